@@ -1,0 +1,163 @@
+"""
+Pins oracle/ (the CPU restatement) against outputs of the reference itself
+(tests/golden/*, produced by tests/golden/make_golden.py in the build
+container).  CPU only.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+from guided_diffusion import synth
+from oracle import sampler_ref, schedule_ref, unet_ref
+
+PUBLISHED = dict(large_size=96, num_channels=128, num_res_blocks=2, num_head_channels=64,
+                 attention_resolutions="1000", learn_sigma=True, resblock_updown=True,
+                 use_scale_shift_norm=True)
+TINY = dict(PUBLISHED, num_channels=32, num_res_blocks=1)
+
+TABLES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next",
+          "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod",
+          "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+          "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"]
+
+
+@pytest.mark.parametrize("tag,resp", [("full", ""), ("250", "250"), ("50", "50"),
+                                      ("ddim50", "ddim50"), ("10", "10"), ("sect", "10,15,20")])
+def test_schedule_tables_exact(golden, tag, resp):
+    g = golden("schedules.npz")
+    tmap, tb = schedule_ref.spaced_schedule(1000, "linear", resp)
+    assert list(g[tag + "/timestep_map"]) == tmap
+    for n in TABLES:
+        assert np.array_equal(g[tag + "/" + n], tb[n]), n   # exact fp64
+
+
+def test_cosine_betas(golden):
+    # d.betas of a SpacedDiffusion is recomputed from the cumulative product
+    # (respace.py:79-83), also when every step is kept.
+    _, tb = schedule_ref.spaced_schedule(100, "cosine", "")
+    assert np.array_equal(golden("schedules.npz")["cos100/betas"], tb["betas"])
+
+
+def test_timestep_embedding(golden):
+    g = golden("timestep_embedding.npz")
+    t = torch.from_numpy(g["t"])
+    for dim, key in [(128, "e128"), (32, "e32"), (33, "e33")]:
+        assert np.array_equal(unet_ref.timestep_embedding(t, dim).numpy(), g[key])
+
+
+def _sd(cfg, seed=0):
+    return {k: torch.from_numpy(v)
+            for k, v in synth.synth_state_dict(unet_ref.param_shapes(cfg), seed).items()}
+
+
+def test_state_dict_keys_match_reference():
+    with open(os.path.join(GOLDEN, "state_keys.json")) as f:
+        ref = json.load(f)
+    cases = {
+        "tiny": unet_ref.sr_config(**TINY),
+        "published": unet_ref.sr_config(**PUBLISHED),
+        "tiny_attn": unet_ref.sr_config(**dict(TINY, large_size=32, attention_resolutions="8,4",
+                                               num_head_channels=32)),
+        "tiny_ls64": unet_ref.sr_config(**dict(TINY, large_size=64)),
+    }
+    for tag, cfg in cases.items():
+        mine = [(k, list(s)) for k, s in unet_ref.param_shapes(cfg)]
+        assert mine == [(x[0], x[1]) for x in ref[tag]], tag
+    n = sum(int(np.prod(s)) for _, s in unet_ref.param_shapes(cases["published"]))
+    assert n == ref["published_param_count"] == 206964610
+
+
+def test_resblocks(golden):
+    g = golden("resblocks.npz")
+    for tag, cin, cout, ud in [("plain", 32, 32, None), ("widen", 32, 64, None),
+                               ("narrow", 64, 32, None), ("down", 32, 32, "down"),
+                               ("up", 32, 32, "up")]:
+        shapes = [("in_layers.0.weight", (cin,)), ("in_layers.0.bias", (cin,)),
+                  ("in_layers.2.weight", (cout, cin, 3, 3, 3)), ("in_layers.2.bias", (cout,)),
+                  ("emb_layers.1.weight", (2 * cout, 128)), ("emb_layers.1.bias", (2 * cout,)),
+                  ("out_layers.0.weight", (cout,)), ("out_layers.0.bias", (cout,)),
+                  ("out_layers.3.weight", (cout, cout, 3, 3, 3)), ("out_layers.3.bias", (cout,))]
+        if cin != cout:
+            shapes += [("skip_connection.weight", (cout, cin, 1, 1, 1)),
+                       ("skip_connection.bias", (cout,))]
+        sd = {"rb." + k: torch.from_numpy(synth.synth_param("rb_%s.%s" % (tag, k), s))
+              for k, s in shapes}
+        rng = np.random.default_rng(7)
+        x = torch.from_numpy(rng.standard_normal((2, cin, 4, 8, 8), dtype=np.float32))
+        emb = torch.from_numpy(rng.standard_normal((2, 128), dtype=np.float32))
+        y = unet_ref.resblock(sd, "rb", x, emb, ud, True)
+        assert rel_err(y.numpy(), g[tag + "/y"]) < 1e-6, tag
+
+
+def _run(cfg, shape, t_vals, seed=0):
+    sd = _sd(cfg, seed)
+    x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0])
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234))
+    t = torch.tensor(t_vals[:shape[0]], dtype=torch.long)
+    with torch.no_grad():
+        return unet_ref.unet_forward(sd, cfg, x, t, lr).numpy()
+
+
+@pytest.mark.parametrize("tag,over,shape,t", [
+    ("tiny_8x16x16", {}, (2, 1, 8, 16, 16), [37, 999]),
+    ("tiny_32", {}, (1, 1, 32, 32, 32), [500]),
+    ("tiny_odd", {}, (1, 1, 5, 48, 16), [3]),
+    ("tiny_attn", dict(large_size=32, attention_resolutions="8,4", num_head_channels=32),
+     (1, 1, 8, 32, 32), [10]),
+    ("tiny_midattn", dict(large_size=32, attention_resolutions="1000", num_head_channels=32,
+                          mid_attention=True), (1, 1, 4, 32, 32), [77]),
+    ("tiny_convresample", dict(resblock_updown=False), (1, 1, 4, 16, 16), [5]),
+    ("tiny_additive", dict(use_scale_shift_norm=False), (1, 1, 4, 16, 16), [5]),
+    ("tiny_nosigma", dict(learn_sigma=False), (1, 1, 4, 16, 16), [5]),
+    ("tiny_ls64", dict(large_size=64), (1, 1, 4, 16, 16), [5]),
+])
+def test_unet_forward_tiny(golden, tag, over, shape, t):
+    cfg = unet_ref.sr_config(**dict(TINY, **over))
+    y = _run(cfg, shape, t)
+    ref = golden("unet_forward.npz")[tag]
+    assert y.shape == ref.shape
+    # same ATen ops in the same order as the reference -> agreement to rounding
+    assert rel_err(y, ref) < 1e-6, tag
+
+
+def test_unet_forward_published_arch(golden):
+    cfg = unet_ref.sr_config(**PUBLISHED)
+    y = _run(cfg, (1, 1, 8, 32, 32), [251])
+    assert rel_err(y, golden("unet_forward.npz")["published_8x32x32"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag,over,shape,resp,kind,eta,kw", [
+    ("ddpm10_32", {}, (1, 1, 32, 32, 32), "10", "ddpm", 0.0, {}),
+    ("ddim10_8x16x16", {}, (2, 1, 8, 16, 16), "ddim10", "ddim", 0.0, {}),
+    ("ddim10_eta_8x16x16", {}, (1, 1, 8, 16, 16), "ddim10", "ddim", 0.5, {}),
+    ("ddpm10_nosigma", dict(learn_sigma=False), (1, 1, 4, 16, 16), "10", "ddpm", 0.0, {}),
+    ("ddpm10_noclip", {}, (1, 1, 4, 16, 16), "10", "ddpm", 0.0, dict(clip_denoised=False)),
+    ("ddpm10_xstart", {}, (1, 1, 4, 16, 16), "10", "ddpm", 0.0, dict(predict_xstart=True)),
+])
+def test_sampler_loops(golden, tag, over, shape, resp, kind, eta, kw):
+    cfg = unet_ref.sr_config(**dict(TINY, **over))
+    sd = _sd(cfg)
+    learn_sigma = dict(TINY, **over)["learn_sigma"]
+    tmap, tb = schedule_ref.spaced_schedule(1000, "linear", resp)
+    draws = [torch.from_numpy(a) for a in synth.synth_noise(shape, len(tmap) + 1, seed=10)]
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234))
+
+    def model_fn(x, t, low_res):
+        return unet_ref.unet_forward(sd, cfg, x, t, low_res)
+
+    trace = []
+    with torch.no_grad():
+        if kind == "ddpm":
+            out = sampler_ref.p_sample_loop(model_fn, tmap, tb, draws[0], draws[1:], lr,
+                                            learn_sigma=learn_sigma, trace=trace, **kw)
+        else:
+            out = sampler_ref.ddim_sample_loop(model_fn, tmap, tb, draws[0], draws[1:], lr,
+                                               eta=eta, learn_sigma=learn_sigma, trace=trace, **kw)
+    g = golden("sampler.npz")
+    assert rel_err(out.numpy(), g[tag + "/sample"]) < 1e-5, tag
+    assert np.allclose(np.array(trace), g[tag + "/trace"], rtol=1e-4, atol=1e-5)
