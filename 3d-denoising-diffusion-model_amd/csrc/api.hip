@@ -1,0 +1,187 @@
+// C ABI (include/ddpm3d.h): argument validation + launcher calls.  Nothing
+// here allocates or synchronises; every entry point only enqueues on `stream`.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include "conv3d_params.h"
+#include "ddpm3d.h"
+#include "ops.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int launched(hipError_t e, const char* what) {
+    if (e == hipSuccess) return DDPM3D_OK;
+    return fail(DDPM3D_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" {
+
+int ddpm3d_abi_version(void) { return DDPM3D_ABI_VERSION; }
+const char* ddpm3d_last_error(void) { return g_err; }
+
+size_t ddpm3d_packed_weight_elems(int Cout, int Cin, int ksize) {
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    return (size_t)ksize * ksize * ksize * ddpm3d_cin_pad(Cin) * ddpm3d_cout_pad(Cout);
+}
+
+int ddpm3d_pack_conv_weight(const float* w, int Cout, int Cin, int ksize, float* out, void* stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3))
+        return fail(DDPM3D_EINVAL, "pack_conv_weight: bad arguments (Cout=%d Cin=%d k=%d)", Cout, Cin, ksize);
+    if (!aligned16(out)) return fail(DDPM3D_EINVAL, "pack_conv_weight: w_packed must be 16-byte aligned");
+    return launched(ddpm3d_launch_pack(w, Cout, Cin, ksize, out, (hipStream_t)stream), "pack_conv_weight");
+}
+
+static void conv_tiles(const ConvCfg& c, int D, int H, int W, int* tz, int* ty, int* tx) {
+    const int TX = 1 << c.TXL, TY = 1 << c.TYL, TZ = 128 / (TX * TY);
+    *tx = (W + TX - 1) / TX;
+    *ty = (H + TY - 1) / TY;
+    *tz = (D + TZ - 1) / TZ;
+}
+
+int ddpm3d_conv_stats_rows(int D, int H, int W, int Cout, int ksize) {
+    if (D <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    const ConvCfg c = ddpm3d_conv_cfg(H, W, Cout, ksize);
+    int tz, ty, tx;
+    conv_tiles(c, D, H, W, &tz, &ty, &tx);
+    return tz * ty * tx * (4 / c.WN);
+}
+
+int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
+    if (!d) return fail(DDPM3D_EINVAL, "conv3d: null descriptor");
+    if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->Cin <= 0)
+        return fail(DDPM3D_EINVAL, "conv3d: non-positive shape N=%d D=%d H=%d W=%d Cin=%d Cout=%d", d->N, d->D,
+                    d->H, d->W, d->Cin, d->Cout);
+    if (d->ksize != 1 && d->ksize != 3) return fail(DDPM3D_EINVAL, "conv3d: ksize %d (1 or 3)", d->ksize);
+    if (d->precision != 0) return fail(DDPM3D_ENOSUP, "conv3d: precision mode %d not implemented", d->precision);
+    if (d->C0 + d->C1 != d->Cin) return fail(DDPM3D_EINVAL, "conv3d: C0+C1 != Cin");
+    if (!d->src0 || !d->w_packed || !d->bias || !d->out) return fail(DDPM3D_EINVAL, "conv3d: null buffer");
+    if (d->in_mode == DDPM3D_IN_PLANAR2) {
+        if (d->Cin != 2 || d->C0 != 1 || d->C1 != 1 || !d->src1 || d->aff_a)
+            return fail(DDPM3D_EINVAL, "conv3d: planar2 input needs C0=C1=1, two planes, no affine");
+    } else {
+        if (d->in_mode < 0 || d->in_mode > 3) return fail(DDPM3D_EINVAL, "conv3d: in_mode %d", d->in_mode);
+        if (d->Cin % DDPM3D_CONV_CK) return fail(DDPM3D_EINVAL, "conv3d: Cin=%d not a multiple of %d", d->Cin, DDPM3D_CONV_CK);
+        if (d->C1 > 0 && (d->C0 % DDPM3D_CONV_CK || !d->src1))
+            return fail(DDPM3D_EINVAL, "conv3d: concat needs C0 %% %d == 0 and src1", DDPM3D_CONV_CK);
+        if (!aligned16(d->src0) || (d->src1 && !aligned16(d->src1)))
+            return fail(DDPM3D_EINVAL, "conv3d: sources must be 16-byte aligned");
+        if (d->in_mode == DDPM3D_IN_UP && ((d->H | d->W) & 1))
+            return fail(DDPM3D_EINVAL, "conv3d: upsampled input needs even H, W (got %d, %d)", d->H, d->W);
+    }
+    if ((d->aff_a == nullptr) != (d->aff_b == nullptr)) return fail(DDPM3D_EINVAL, "conv3d: aff_a/aff_b must come together");
+    if (d->aff_a && (!aligned16(d->aff_a) || !aligned16(d->aff_b)))
+        return fail(DDPM3D_EINVAL, "conv3d: affine tables must be 16-byte aligned");
+    if (!aligned16(d->w_packed)) return fail(DDPM3D_EINVAL, "conv3d: w_packed must be 16-byte aligned");
+    if (d->res_mode < 0 || d->res_mode > 3 || (d->res_mode != DDPM3D_RES_NONE && !d->res))
+        return fail(DDPM3D_EINVAL, "conv3d: residual mode %d without / with bad buffer", d->res_mode);
+    if (d->res_mode == DDPM3D_RES_UP && ((d->H | d->W) & 1))
+        return fail(DDPM3D_EINVAL, "conv3d: upsampled residual needs even H, W");
+    if (d->bias_stride_n < 0) return fail(DDPM3D_EINVAL, "conv3d: negative bias_stride_n");
+    if (d->out_layout != DDPM3D_OUT_NDHWC && d->out_layout != DDPM3D_OUT_NCDHW)
+        return fail(DDPM3D_EINVAL, "conv3d: out_layout %d", d->out_layout);
+
+    const ConvCfg c = ddpm3d_conv_cfg(d->H, d->W, d->Cout, d->ksize);
+    ConvK k;
+    memset(&k, 0, sizeof(k));
+    k.src0 = d->src0; k.src1 = d->src1; k.affA = d->aff_a; k.affB = d->aff_b;
+    k.w = d->w_packed; k.bias = d->bias; k.res = d->res; k.out = d->out; k.stats = d->stats;
+    k.N = d->N; k.D = d->D; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Cout = d->Cout;
+    k.C0 = d->C0; k.C1 = d->C1;
+    k.CinPad = ddpm3d_cin_pad(d->Cin); k.CoutPad = ddpm3d_cout_pad(d->Cout);
+    k.in_mode = d->in_mode; k.act = d->act; k.bias_stride_n = d->bias_stride_n;
+    k.res_mode = d->res_mode; k.out_layout = d->out_layout;
+    conv_tiles(c, d->D, d->H, d->W, &k.tilesZ, &k.tilesY, &k.tilesX);
+    k.stats_rows = k.tilesZ * k.tilesY * k.tilesX * (4 / c.WN);
+    if (d->stats && d->stats_rows != k.stats_rows)
+        return fail(DDPM3D_EINVAL, "conv3d: stats_rows=%d, this shape writes %d", d->stats_rows, k.stats_rows);
+    if (d->stats && d->out_layout != DDPM3D_OUT_NDHWC)
+        return fail(DDPM3D_EINVAL, "conv3d: statistics only with NDHWC output");
+    const long long blocks = (long long)k.N * k.tilesZ * k.tilesY * k.tilesX;
+    if (blocks > 0x7fffffffLL) return fail(DDPM3D_EINVAL, "conv3d: grid too large");
+    return launched(ddpm3d_launch_conv_f32(k, c, (hipStream_t)stream), "conv3d");
+}
+
+int ddpm3d_gn_finalize(const float* stats0, int C0, int rows0, const float* stats1, int C1, int rows1,
+                       int N, int groups, double count, float eps, const float* gamma, const float* beta,
+                       const float* film, int film_stride, int film_off, float* aff_a, float* aff_b,
+                       void* stream) {
+    const int C = C0 + C1;
+    if (!stats0 || !gamma || !beta || !aff_a || !aff_b || N <= 0 || groups <= 0 || C0 <= 0 || C1 < 0 ||
+        rows0 <= 0 || count <= 0)
+        return fail(DDPM3D_EINVAL, "gn_finalize: bad arguments");
+    if (C % groups) return fail(DDPM3D_EINVAL, "gn_finalize: C=%d not divisible by %d groups", C, groups);
+    const int cg = C / groups;
+    if (C1 > 0 && (!stats1 || rows1 <= 0 || C0 % cg))
+        return fail(DDPM3D_EINVAL, "gn_finalize: a group straddles the concat boundary (C0=%d, group=%d)", C0, cg);
+    return launched(ddpm3d_launch_gn_finalize(stats0, C0, rows0, stats1, C1, rows1, N, groups, count, eps,
+                                              gamma, beta, film, film_stride, film_off, aff_a, aff_b,
+                                              (hipStream_t)stream),
+                    "gn_finalize");
+}
+
+int ddpm3d_gn_stats_rows(int voxels) { return voxels > 0 ? ddpm3d_gn_stats_rows_impl(voxels) : 0; }
+
+int ddpm3d_gn_stats(const float* x, int N, int voxels, int C, float* stats, void* stream) {
+    if (!x || !stats || N <= 0 || voxels <= 0 || C <= 0 || (C & 3) || !aligned16(x))
+        return fail(DDPM3D_EINVAL, "gn_stats: bad arguments (C must be a multiple of 4, x 16-byte aligned)");
+    return launched(ddpm3d_launch_gn_stats(x, N, voxels, C, stats, (hipStream_t)stream), "gn_stats");
+}
+
+int ddpm3d_timestep_embedding(const float* t, int rows, int dim, float max_period, float* out, void* stream) {
+    if (!t || !out || rows <= 0 || dim <= 1) return fail(DDPM3D_EINVAL, "timestep_embedding: bad arguments");
+    return launched(ddpm3d_launch_timestep_embedding(t, rows, dim, max_period, out, (hipStream_t)stream),
+                    "timestep_embedding");
+}
+
+int ddpm3d_linear(const float* in, int rows, int K, const float* w, const float* bias, int O, int silu_in,
+                  float* out, int out_stride, void* stream) {
+    if (!in || !w || !bias || !out || rows <= 0 || K <= 0 || O <= 0 || out_stride < O)
+        return fail(DDPM3D_EINVAL, "linear: bad arguments");
+    return launched(ddpm3d_launch_linear(in, rows, K, w, bias, O, silu_in, out, out_stride, (hipStream_t)stream),
+                    "linear");
+}
+
+int ddpm3d_ncdhw_to_ndhwc(const float* in, int N, int C, int voxels, float* out, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || voxels <= 0) return fail(DDPM3D_EINVAL, "ncdhw_to_ndhwc: bad arguments");
+    return launched(ddpm3d_launch_transpose(in, N, C, voxels, out, (hipStream_t)stream), "ncdhw_to_ndhwc");
+}
+int ddpm3d_ndhwc_to_ncdhw(const float* in, int N, int C, int voxels, float* out, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || voxels <= 0) return fail(DDPM3D_EINVAL, "ndhwc_to_ncdhw: bad arguments");
+    return launched(ddpm3d_launch_transpose(in, N, voxels, C, out, (hipStream_t)stream), "ndhwc_to_ncdhw");
+}
+
+static int step_args_ok(const float* mo, const float* x, const float* noise, const float* coef,
+                        const int64_t* t, int N, int voxels, float* sample) {
+    return mo && x && noise && coef && t && sample && N > 0 && voxels > 0;
+}
+
+int ddpm3d_p_sample_step(const float* model_out, const float* x, const float* noise, const float* coef,
+                         const int64_t* t_idx, int N, int voxels, int flags, float* sample,
+                         float* pred_xstart, void* stream) {
+    if (!step_args_ok(model_out, x, noise, coef, t_idx, N, voxels, sample))
+        return fail(DDPM3D_EINVAL, "p_sample_step: bad arguments");
+    return launched(ddpm3d_launch_sample_step(false, model_out, x, noise, coef, t_idx, N, voxels, flags, 0.0f,
+                                              sample, pred_xstart, (hipStream_t)stream),
+                    "p_sample_step");
+}
+
+int ddpm3d_ddim_step(const float* model_out, const float* x, const float* noise, const float* coef,
+                     const int64_t* t_idx, int N, int voxels, int flags, float eta, float* sample,
+                     float* pred_xstart, void* stream) {
+    if (!step_args_ok(model_out, x, noise, coef, t_idx, N, voxels, sample))
+        return fail(DDPM3D_EINVAL, "ddim_step: bad arguments");
+    return launched(ddpm3d_launch_sample_step(true, model_out, x, noise, coef, t_idx, N, voxels, flags, eta,
+                                              sample, pred_xstart, (hipStream_t)stream),
+                    "ddim_step");
+}
+
+}  // extern "C"

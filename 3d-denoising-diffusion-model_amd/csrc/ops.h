@@ -1,0 +1,20 @@
+// Internal launcher prototypes (definitions in ops.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, float* out, hipStream_t st);
+hipError_t ddpm3d_launch_gn_finalize(const float* st0, int C0, int rows0, const float* st1, int C1,
+                                     int rows1, int N, int groups, double count, float eps,
+                                     const float* gamma, const float* beta, const float* film,
+                                     int film_stride, int film_off, float* A, float* B, hipStream_t st);
+hipError_t ddpm3d_launch_gn_stats(const float* x, int N, int voxels, int C, float* stats, hipStream_t st);
+int ddpm3d_gn_stats_rows_impl(int voxels);
+hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, float max_period,
+                                            float* out, hipStream_t st);
+hipError_t ddpm3d_launch_linear(const float* in, int rows, int K, const float* w, const float* bias, int O,
+                                int silu_in, float* out, int out_stride, hipStream_t st);
+hipError_t ddpm3d_launch_transpose(const float* in, int N, int R, int S, float* out, hipStream_t st);
+hipError_t ddpm3d_launch_sample_step(bool ddim, const float* mo, const float* x, const float* noise,
+                                     const float* coef, const int64_t* t_idx, int N, int voxels, int flags,
+                                     float eta, float* sample, float* pred_xstart, hipStream_t st);

@@ -1,0 +1,333 @@
+// Small gfx950 kernels around the conv: weight packing, GroupNorm statistics
+// folding, timestep embedding, Linear, layout changes and the per-step
+// sampler update.  All HBM- or latency-bound; wave64 throughout.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv3d_params.h"
+#include "ops.h"
+
+// ------------------------------------------------------------------ packing
+// OIDHW -> [tap][ci/8][CoutPad][8]  (zero padded in ci and cout).  The inner 8
+// is the channel within the 8-block; lane half h of the conv reads [4h, 4h+4).
+__global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
+                                   int CoutPad, int CinPad, float* __restrict__ out) {
+    const size_t total = (size_t)taps * CinPad * CoutPad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        size_t r = i >> 3;
+        const int co = (int)(r % CoutPad); r /= CoutPad;
+        const int cb = (int)(r % (CinPad / 8));
+        const int tap = (int)(r / (CinPad / 8));
+        const int ci = cb * 8 + j;
+        float v = 0.0f;
+        if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * taps + tap];
+        out[i] = v;
+    }
+}
+
+hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, float* out, hipStream_t st) {
+    const int taps = ks * ks * ks;
+    const int CoutPad = ddpm3d_cout_pad(Cout), CinPad = ddpm3d_cin_pad(Cin);
+    const size_t total = (size_t)taps * CinPad * CoutPad;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w, Cout, Cin, taps, CoutPad,
+                       CinPad, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------- wave helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------- GN finalize
+// One workgroup per (n, group): fold partial (sum, sumsq) rows in fp64, then
+// write A, B for the group's channels.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(
+    const float* __restrict__ st0, int C0, int rows0, const float* __restrict__ st1, int C1, int rows1,
+    int groups, double count, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ film, int film_stride, int film_off, float* __restrict__ A,
+    float* __restrict__ B) {
+    const int C = C0 + C1;
+    const int cg = C / groups;
+    const int n = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cbeg = g * cg;
+    const bool from0 = cbeg < C0;
+    const float* st = from0 ? st0 : st1;
+    const int Cs = from0 ? C0 : C1;
+    const int rows = from0 ? rows0 : rows1;
+    const int cs = from0 ? cbeg : cbeg - C0;
+    double s1 = 0.0, s2 = 0.0;
+    const int items = rows * cg;
+    for (int i = threadIdx.x; i < items; i += blockDim.x) {
+        const int r = i / cg, c = i - r * cg;
+        const float2 v = *reinterpret_cast<const float2*>(st + (((size_t)n * rows + r) * Cs + cs + c) * 2);
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+    }
+    __shared__ double red[2][4];
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const double cnt = count * cg;
+    const double mean = s1 / cnt;
+    double var = s2 / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    for (int c = threadIdx.x; c < cg; c += blockDim.x) {
+        const int ch = cbeg + c;
+        float a = rstd * gamma[ch];
+        float b = fmaf(-meanf, a, beta[ch]);
+        if (film != nullptr) {
+            const float sc = 1.0f + film[(size_t)n * film_stride + film_off + ch];
+            const float sh = film[(size_t)n * film_stride + film_off + C + ch];
+            a = a * sc;
+            b = fmaf(b, sc, sh);
+        }
+        A[(size_t)n * C + ch] = a;
+        B[(size_t)n * C + ch] = b;
+    }
+}
+
+hipError_t ddpm3d_launch_gn_finalize(const float* st0, int C0, int rows0, const float* st1, int C1,
+                                     int rows1, int N, int groups, double count, float eps,
+                                     const float* gamma, const float* beta, const float* film,
+                                     int film_stride, int film_off, float* A, float* B, hipStream_t st) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, st, st0, C0, rows0, st1, C1,
+                       rows1, groups, count, eps, gamma, beta, film, film_stride, film_off, A, B);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------- GN stats
+// Stand-alone statistics pass for NDHWC tensors no conv epilogue produced.
+// One workgroup per (n, row of GN_STATS_VOX voxels): thread c-strided over
+// channels, 16-byte loads along C.
+#define GN_STATS_VOX 256
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int voxels, int C,
+                                                       int rows, float* __restrict__ stats) {
+    const int n = blockIdx.x / rows, r = blockIdx.x % rows;
+    const int v0 = r * GN_STATS_VOX;
+    const int v1 = min(v0 + GN_STATS_VOX, voxels);
+    const int C4 = C / 4;
+    // thread -> (channel quad, voxel lane); quads fastest so a wave reads contiguous bytes
+    const int qpt = min(C4, 256);
+    const int vlanes = 256 / qpt;
+    __shared__ float sh[2][256 * 4];
+    for (int q0 = 0; q0 < C4; q0 += qpt) {
+        const int q = q0 + (threadIdx.x % qpt);
+        const int vl = threadIdx.x / qpt;
+        float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+        if (q < C4 && vl < vlanes) {
+            for (int v = v0 + vl; v < v1; v += vlanes) {
+                const float4 t = *reinterpret_cast<const float4*>(x + ((size_t)n * voxels + v) * C + q * 4);
+                s1[0] += t.x; s1[1] += t.y; s1[2] += t.z; s1[3] += t.w;
+                s2[0] = fmaf(t.x, t.x, s2[0]); s2[1] = fmaf(t.y, t.y, s2[1]);
+                s2[2] = fmaf(t.z, t.z, s2[2]); s2[3] = fmaf(t.w, t.w, s2[3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sh[0][threadIdx.x * 4 + i] = s1[i]; sh[1][threadIdx.x * 4 + i] = s2[i]; }
+        __syncthreads();
+        if (threadIdx.x < qpt && q < C4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a = 0.f, b = 0.f;
+                for (int l = 0; l < vlanes; ++l) {
+                    a += sh[0][(l * qpt + threadIdx.x) * 4 + i];
+                    b += sh[1][(l * qpt + threadIdx.x) * 4 + i];
+                }
+                float* o = stats + (((size_t)n * rows + r) * C + q * 4 + i) * 2;
+                o[0] = a;
+                o[1] = b;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t ddpm3d_launch_gn_stats(const float* x, int N, int voxels, int C, float* stats, hipStream_t st) {
+    const int rows = (voxels + GN_STATS_VOX - 1) / GN_STATS_VOX;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(N * rows), dim3(256), 0, st, x, voxels, C, rows, stats);
+    return hipGetLastError();
+}
+int ddpm3d_gn_stats_rows_impl(int voxels) { return (voxels + GN_STATS_VOX - 1) / GN_STATS_VOX; }
+
+// ------------------------------------------------------ timestep embedding
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int rows, int dim, float max_period,
+                                          float* __restrict__ out) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * dim) return;
+    const int r = i / dim, j = i - r * dim;
+    float v = 0.0f;
+    if (j < 2 * half) {
+        const int f = j < half ? j : j - half;
+        // freqs = exp(-ln(max_period) * f / half), fp32 like nn.py:113-115
+        const float freq = expf(-logf(max_period) * (float)f / (float)half);
+        const float arg = t[r] * freq;
+        v = j < half ? cosf(arg) : sinf(arg);
+    }
+    out[i] = v;
+}
+
+hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, float max_period,
+                                            float* out, hipStream_t st) {
+    const int total = rows * dim;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, st, t, rows, dim,
+                       max_period, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ linear
+// One wave per output feature o, LIN_ROWS rows of the batch at a time: the
+// weight row is read once (coalesced 256-B segments) and reused across rows.
+#define LIN_ROWS 8
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ in, int rows, int K,
+                                                     const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int O, int silu_in,
+                                                     float* __restrict__ out, int out_stride) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = blockIdx.y * LIN_ROWS;
+    if (o >= O) return;
+    float acc[LIN_ROWS];
+#pragma unroll
+    for (int r = 0; r < LIN_ROWS; ++r) acc[r] = 0.0f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = w[(size_t)o * K + k];
+#pragma unroll
+        for (int r = 0; r < LIN_ROWS; ++r) {
+            if (r0 + r < rows) {
+                float xv = in[(size_t)(r0 + r) * K + k];
+                if (silu_in) xv = xv / (1.0f + expf(-xv));
+                acc[r] = fmaf(xv, wv, acc[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < LIN_ROWS; ++r) {
+        const float s = wave_sum(acc[r]);
+        if (lane == 0 && r0 + r < rows) out[(size_t)(r0 + r) * out_stride + o] = s + bias[o];
+    }
+}
+
+hipError_t ddpm3d_launch_linear(const float* in, int rows, int K, const float* w, const float* bias, int O,
+                                int silu_in, float* out, int out_stride, hipStream_t st) {
+    dim3 grid((O + 3) / 4, (rows + LIN_ROWS - 1) / LIN_ROWS);
+    hipLaunchKernelGGL(linear_kernel, grid, dim3(256), 0, st, in, rows, K, w, bias, O, silu_in, out,
+                       out_stride);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------- layouts
+// LDS-tiled transpose between [C][V] and [V][C] per sample (32x32 tiles, +1 pad).
+__global__ __launch_bounds__(256) void transpose_cv_kernel(const float* __restrict__ in, int R, int S,
+                                                           float* __restrict__ out) {
+    // in: [n][R][S] -> out: [n][S][R]
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* src = in + (size_t)n * R * S;
+    float* dst = out + (size_t)n * R * S;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int r = r0 + ty + j, s = s0 + tx;
+        tile[ty + j][tx] = (r < R && s < S) ? src[(size_t)r * S + s] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int s = s0 + ty + j, r = r0 + tx;
+        if (r < R && s < S) dst[(size_t)s * R + r] = tile[tx][ty + j];
+    }
+}
+
+hipError_t ddpm3d_launch_transpose(const float* in, int N, int R, int S, float* out, hipStream_t st) {
+    dim3 grid((S + 31) / 32, (R + 31) / 32, N);
+    hipLaunchKernelGGL(transpose_cv_kernel, grid, dim3(256), 0, st, in, R, S, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------- sampler update
+// The arithmetic order mirrors the reference's torch expressions one rounding
+// at a time, so contraction into FMAs is switched off here.
+#pragma clang fp contract(off)
+
+template <bool DDIM>
+__global__ __launch_bounds__(256) void sample_step_kernel(
+    const float* __restrict__ mo, const float* __restrict__ x, const float* __restrict__ noise,
+    const float* __restrict__ coef, const int64_t* __restrict__ t_idx, int voxels, int flags, float eta,
+    float* __restrict__ sample, float* __restrict__ pred_xstart) {
+    const int n = blockIdx.y;
+    const int64_t ti = t_idx[n];
+    const float* c = coef + (size_t)ti * DDPM3D_NCOEF;
+    const float c_recip = c[DDPM3D_C_SQRT_RECIP_ACP], c_recipm1 = c[DDPM3D_C_SQRT_RECIPM1_ACP];
+    const float c1 = c[DDPM3D_C_POST_MEAN_COEF1], c2 = c[DDPM3D_C_POST_MEAN_COEF2];
+    const float min_log = c[DDPM3D_C_MIN_LOG], max_log = c[DDPM3D_C_MAX_LOG];
+    const float ab = c[DDPM3D_C_ACP], ab_prev = c[DDPM3D_C_ACP_PREV];
+    const bool learn = flags & DDPM3D_F_LEARN_SIGMA;
+    const int ch = learn ? 2 : 1;
+    const float mask = ti != 0 ? 1.0f : 0.0f;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < voxels; v += gridDim.x * blockDim.x) {
+        const size_t i = (size_t)n * voxels + v;
+        const float xv = x[i];
+        const float e = mo[((size_t)n * ch) * voxels + v];
+        float x0;
+        if (flags & DDPM3D_F_PREDICT_XSTART) {
+            x0 = e;
+        } else {
+            x0 = c_recip * xv - c_recipm1 * e;  // gaussian_diffusion.py:330-333
+        }
+        if (flags & DDPM3D_F_CLIP) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        float out;
+        if (!DDIM) {
+            float logvar;
+            if (learn) {
+                const float vv = mo[((size_t)n * ch + 1) * voxels + v];
+                const float frac = (vv + 1.0f) / 2.0f;                      // :274
+                logvar = frac * max_log + (1.0f - frac) * min_log;          // :275
+            } else {
+                logvar = min_log;
+            }
+            const float mean = c1 * x0 + c2 * xv;                           // :216-219
+            out = mean + mask * expf(0.5f * logvar) * noise[i];             // :438
+        } else {
+            const float eps = (c_recip * xv - x0) / c_recipm1;              // :345-349
+            const float sigma = eta * sqrtf((1.0f - ab_prev) / (1.0f - ab)) * sqrtf(1.0f - ab / ab_prev);
+            const float mean_pred = x0 * sqrtf(ab_prev) + sqrtf(1.0f - ab_prev - sigma * sigma) * eps;
+            out = mean_pred + mask * sigma * noise[i];                      // :584
+        }
+        sample[i] = out;
+        if (pred_xstart != nullptr) pred_xstart[i] = x0;
+    }
+}
+
+hipError_t ddpm3d_launch_sample_step(bool ddim, const float* mo, const float* x, const float* noise,
+                                     const float* coef, const int64_t* t_idx, int N, int voxels, int flags,
+                                     float eta, float* sample, float* pred_xstart, hipStream_t st) {
+    int bx = (voxels + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    dim3 grid(bx, N);
+    if (ddim)
+        hipLaunchKernelGGL(sample_step_kernel<true>, grid, dim3(256), 0, st, mo, x, noise, coef, t_idx, voxels,
+                           flags, eta, sample, pred_xstart);
+    else
+        hipLaunchKernelGGL(sample_step_kernel<false>, grid, dim3(256), 0, st, mo, x, noise, coef, t_idx,
+                           voxels, flags, eta, sample, pred_xstart);
+    return hipGetLastError();
+}

@@ -1,0 +1,320 @@
+"""
+Launch-plan compiler for the 3-D UNet forward.
+
+A model (its layer list from unet.py and its parameters) plus an input shape
+(N, D, H, W) is compiled ONCE into a flat list of C-ABI calls with every
+buffer, descriptor and statistics row count fixed; a forward pass replays the
+list.  What the reference does as ~600 ATen calls per step
+(unet.py:1015-1044, :236-256) becomes, per ResBlock,
+
+    gn_finalize -> conv3d(GN+SiLU [+pool/up] prologue, stats epilogue)
+    gn_finalize(FiLM) -> [conv3d k=1 skip] -> conv3d(GN*(1+s)+t, SiLU prologue;
+                                                      + residual, stats epilogue)
+
+Activations live channels-last ([N][D][H][W][C], fp32).  The timestep path
+(timestep_embedding -> time_embed -> every ResBlock's emb_layers) does not
+depend on x, so all emb_layers are fused into one Linear whose output row
+("film row") is either computed per call or, in the samplers, precomputed
+for every step of the schedule.
+"""
+
+import ctypes as C
+
+import torch
+
+from . import _hip as H
+
+
+class Act:
+    """An NDHWC activation produced by a conv epilogue, with its GN partial sums."""
+    __slots__ = ("buf", "C", "D", "H", "W", "stats", "rows")
+
+    def __init__(self, buf, Cn, D, Hh, W, stats, rows):
+        self.buf, self.C, self.D, self.H, self.W, self.stats, self.rows = buf, Cn, D, Hh, W, stats, rows
+
+    @property
+    def voxels(self):
+        return self.D * self.H * self.W
+
+
+class PackedConv:
+    __slots__ = ("w", "b", "Cout", "Cin", "k")
+
+    def __init__(self, weight, bias, stream):
+        lib = H.load()
+        Cout, Cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        n = lib.ddpm3d_packed_weight_elems(Cout, Cin, k)
+        if n == 0:
+            raise RuntimeError("unsupported conv weight shape %s" % (tuple(weight.shape),))
+        w32 = weight.detach().float().contiguous()
+        self.w = torch.empty(n, dtype=torch.float32, device=weight.device)
+        H.check(lib.ddpm3d_pack_conv_weight(H.ptr(w32), Cout, Cin, k, H.ptr(self.w), stream))
+        self.b = bias.detach().float().contiguous()
+        self.Cout, self.Cin, self.k = Cout, Cin, k
+
+
+class UNetEngine:
+    """Executes one model on one device.  `layers` is unet.py's topology."""
+
+    def __init__(self, topo, params, model_channels, film, device):
+        self.lib = H.load()
+        self.topo = topo
+        self.device = device
+        self.mc = model_channels
+        self.film = film  # use_scale_shift_norm
+        self.p = params    # name -> device fp32 tensor
+        self.plans = {}
+        st = H.stream()
+        self.conv = {}
+        for name, t in params.items():
+            if name.endswith(".weight") and t.dim() >= 3:
+                base = name[:-len(".weight")]
+                w = t if t.dim() == 5 else t.reshape(t.shape[0], t.shape[1], 1, 1, 1)
+                self.conv[base] = PackedConv(w, params[base + ".bias"], st)
+        # fuse every ResBlock's emb_layers Linear into one [total, ted] matrix
+        ws, bs, self.film_off = [], [], {}
+        off = 0
+        for entry in topo.all_layers():
+            if entry.kind != "res":
+                continue
+            w = params[entry.prefix + ".emb_layers.1.weight"]
+            b = params[entry.prefix + ".emb_layers.1.bias"]
+            if not film:
+                # additive embedding: h = conv1(.) + emb_out, so the Linear's bias also
+                # carries conv1's bias and its output row is conv1's per-sample bias
+                b = b + params[entry.prefix + ".in_layers.2.bias"]
+            self.film_off[entry.prefix] = off
+            ws.append(w.float())
+            bs.append(b.float())
+            off += w.shape[0]
+        self.film_total = off
+        self.ted = 4 * model_channels
+        self.emb_w = torch.cat(ws, 0).contiguous()
+        self.emb_b = torch.cat(bs, 0).contiguous()
+        torch.cuda.current_stream().synchronize()
+
+    # ------------------------------------------------------------ timestep path
+    def film_rows(self, t_float):
+        """[R] timesteps (float, original-process index) -> [R, film_total]."""
+        lib, st, p = self.lib, H.stream(), self.p
+        R = t_float.numel()
+        dev = self.device
+        temb = torch.empty(R, self.mc, dtype=torch.float32, device=dev)
+        e1 = torch.empty(R, self.ted, dtype=torch.float32, device=dev)
+        e2 = torch.empty(R, self.ted, dtype=torch.float32, device=dev)
+        rows = torch.empty(R, self.film_total, dtype=torch.float32, device=dev)
+        H.check(lib.ddpm3d_timestep_embedding(H.ptr(t_float), R, self.mc, 10000.0, H.ptr(temb), st))
+        H.check(lib.ddpm3d_linear(H.ptr(temb), R, self.mc, H.ptr(p["time_embed.0.weight"]),
+                                  H.ptr(p["time_embed.0.bias"]), self.ted, 0, H.ptr(e1), self.ted, st))
+        H.check(lib.ddpm3d_linear(H.ptr(e1), R, self.ted, H.ptr(p["time_embed.2.weight"]),
+                                  H.ptr(p["time_embed.2.bias"]), self.ted, 1, H.ptr(e2), self.ted, st))
+        H.check(lib.ddpm3d_linear(H.ptr(e2), R, self.ted, H.ptr(self.emb_w), H.ptr(self.emb_b),
+                                  self.film_total, 1, H.ptr(rows), self.film_total, st))
+        return rows
+
+    # ------------------------------------------------------------ plan building
+    def plan(self, N, D, Hh, W):
+        key = (N, D, Hh, W)
+        pl = self.plans.get(key)
+        if pl is None:
+            pl = _Plan(self, N, D, Hh, W)
+            self.plans[key] = pl
+        return pl
+
+    def forward(self, x, low_res, film_rows, film_stride, out=None):
+        """x, low_res: (N,1,D,H,W) device fp32.  film_rows: device tensor whose row n
+        (stride film_stride floats; 0 = one row shared by the batch) holds the
+        fused emb_layers output for sample n.  Returns (N, Cout, D, H, W)."""
+        N, _, D, Hh, W = x.shape
+        pl = self.plan(N, D, Hh, W)
+        return pl.run(x, low_res, film_rows, film_stride, out)
+
+
+class _Plan:
+    def __init__(self, eng, N, D, Hh, W):
+        self.eng = eng
+        self.N = N
+        self.steps = []       # (fn, args) replayed in order
+        self.keep = []        # keeps ctypes structs / tensors alive
+        self.film_patches = []  # gn_finalize arg lists whose film pointer is per call
+        self.bias_patches = []  # (conv desc, film offset): additive-embedding conv1 bias rows
+        dev = eng.device
+        topo = eng.topo
+        lib = eng.lib
+
+        def new_act(Cn, d, h, w, ks=3, stats=True):
+            buf = torch.empty(N * d * h * w * Cn, dtype=torch.float32, device=dev)
+            rows = lib.ddpm3d_conv_stats_rows(d, h, w, Cn, ks)
+            stt = torch.empty(N * rows * Cn * 2, dtype=torch.float32, device=dev) if stats else None
+            return Act(buf, Cn, d, h, w, stt, rows)
+
+        self.new_act = new_act
+        first = topo.input[0][0]
+        cin_conv = eng.conv[first.prefix]
+        self.first_desc = None
+        h = new_act(cin_conv.Cout, D, Hh, W)
+        self.first_desc = self.conv_step(cin_conv, srcs=None, out=h, planar=True)
+        hs = [h]
+        for blk in topo.input[1:]:
+            for e in blk:
+                h = self.layer(e, [h])
+            hs.append(h)
+        for e in topo.middle:
+            h = self.layer(e, [h])
+        for blk in topo.output:
+            skip = hs.pop()
+            srcs = [h, skip]
+            for e in blk:
+                h = self.layer(e, srcs)
+                srcs = [h]
+        # out: GN -> SiLU -> conv, stored NCDHW
+        A, B = self.finalize([h], "out.0", None)
+        oc = eng.conv["out.2"]
+        self.out_C = oc.Cout
+        self.out_shape = (N, oc.Cout, D, Hh, W)
+        self.out_buf = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
+        self.last_desc = self.conv_step(oc, srcs=[h], out=None, aff=(A, B), act=H.ACT_SILU,
+                                        out_tensor=self.out_buf, out_layout=H.OUT_NCDHW)
+
+    # ---- helpers -------------------------------------------------------------
+    def finalize(self, srcs, gn_prefix, film_prefix):
+        """gn_finalize over the virtual concat of `srcs`; returns (A, B) tensors."""
+        eng, N = self.eng, self.N
+        Cn = sum(s.C for s in srcs)
+        A = torch.empty(N * Cn, dtype=torch.float32, device=eng.device)
+        B = torch.empty(N * Cn, dtype=torch.float32, device=eng.device)
+        s0 = srcs[0]
+        s1 = srcs[1] if len(srcs) > 1 else None
+        if s1 is not None and s1.voxels != s0.voxels:
+            raise RuntimeError("concat of tensors with different spatial size")
+        gamma = eng.p[gn_prefix + ".weight"]
+        beta = eng.p[gn_prefix + ".bias"]
+        args = [H.ptr(s0.stats), s0.C, s0.rows,
+                H.ptr(s1.stats) if s1 else 0, s1.C if s1 else 0, s1.rows if s1 else 0,
+                N, 32, float(s0.voxels), 1e-5, H.ptr(gamma), H.ptr(beta),
+                0, 0, 0, H.ptr(A), H.ptr(B), 0]
+        if film_prefix is not None:
+            args[14] = eng.film_off[film_prefix]
+            self.film_patches.append(args)
+        self.steps.append((eng.lib.ddpm3d_gn_finalize, args))
+        self.keep += [A, B]
+        return A, B
+
+    def conv_step(self, pc, srcs, out, aff=None, act=H.ACT_NONE, in_mode=H.IN_SAME, res=None,
+                  res_mode=H.RES_NONE, planar=False, out_tensor=None, out_layout=H.OUT_NDHWC,
+                  bias_per_n=False, want_stats=True):
+        N = self.N
+        d = H.ConvDesc()
+        if out is not None:
+            d.N, d.D, d.H, d.W = N, out.D, out.H, out.W
+            d.out = H.ptr(out.buf)
+            d.stats = H.ptr(out.stats) if want_stats else 0
+            d.stats_rows = out.rows if want_stats else 0
+        else:
+            s = srcs[0]
+            d.N, d.D, d.H, d.W = N, s.D, s.H, s.W
+            d.out = H.ptr(out_tensor)
+            d.stats = 0
+            d.stats_rows = 0
+        d.Cout, d.ksize = pc.Cout, pc.k
+        d.out_layout = out_layout
+        if planar:
+            d.in_mode, d.Cin, d.C0, d.C1 = H.IN_PLANAR2, 2, 1, 1
+        else:
+            d.in_mode = in_mode
+            d.src0, d.C0 = H.ptr(srcs[0].buf), srcs[0].C
+            if len(srcs) > 1:
+                d.src1, d.C1 = H.ptr(srcs[1].buf), srcs[1].C
+            d.Cin = d.C0 + d.C1
+            if d.Cin != pc.Cin:
+                raise RuntimeError("conv %dx%d fed %d channels" % (pc.Cout, pc.Cin, d.Cin))
+        if aff is not None:
+            d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
+        d.act = act
+        d.w_packed, d.bias = H.ptr(pc.w), H.ptr(pc.b)
+        d.bias_stride_n = 0  # per-sample bias rows are patched in run()
+        d.res_mode = res_mode
+        d.res = H.ptr(res.buf) if res is not None else 0
+        self.keep.append(d)
+        self.steps.append((self.eng.lib.ddpm3d_conv3d, [C.byref(d), 0]))
+        return d
+
+    def layer(self, e, srcs):
+        eng = self.eng
+        if e.kind == "res":
+            return self.resblock(e, srcs)
+        if e.kind == "upconv":
+            x = srcs[0]
+            pc = eng.conv[e.prefix + ".conv"]
+            y = self.new_act(pc.Cout, x.D, x.H * 2, x.W * 2)
+            self.conv_step(pc, [x], y, in_mode=H.IN_UP)
+            return y
+        if e.kind == "attn":
+            raise NotImplementedError(
+                "attention blocks (AttentionBlock, unet.py:259-305) are not yet available in the "
+                "HIP engine; the published model (SuperResModel_noatt with "
+                "--attention_resolutions 1000) has none")
+        if e.kind == "downconv":
+            raise NotImplementedError(
+                "strided-conv Downsample (resblock_updown=False) is not yet available in the HIP "
+                "engine; the published model uses --resblock_updown True")
+        raise ValueError(e.kind)
+
+    def resblock(self, e, srcs):
+        eng = self.eng
+        p = e.prefix
+        x0 = srcs[0]
+        if e.updown == "down":
+            if (x0.H | x0.W) & 1:
+                raise RuntimeError("Downsample needs even H, W (got %dx%d)" % (x0.H, x0.W))
+            d, h, w, im, rm = x0.D, x0.H // 2, x0.W // 2, H.IN_POOL, H.RES_POOL
+        elif e.updown == "up":
+            d, h, w, im, rm = x0.D, x0.H * 2, x0.W * 2, H.IN_UP, H.RES_UP
+        else:
+            d, h, w, im, rm = x0.D, x0.H, x0.W, H.IN_SAME, H.RES_SAME
+        c1 = eng.conv[p + ".in_layers.2"]
+        c2 = eng.conv[p + ".out_layers.3"]
+        A1, B1 = self.finalize(srcs, p + ".in_layers.0", None)
+        h1 = self.new_act(c1.Cout, d, h, w)
+        if eng.film:
+            self.conv_step(c1, srcs, h1, aff=(A1, B1), act=H.ACT_SILU, in_mode=im)
+            A2, B2 = self.finalize([h1], p + ".out_layers.0", p)
+        else:
+            # additive embedding: conv1's bias is the per-sample film row slice
+            dsc = self.conv_step(c1, srcs, h1, aff=(A1, B1), act=H.ACT_SILU, in_mode=im, bias_per_n=True)
+            self.bias_patches.append((dsc, eng.film_off[p]))
+            A2, B2 = self.finalize([h1], p + ".out_layers.0", None)
+        y = self.new_act(c2.Cout, d, h, w)
+        skip = eng.conv.get(p + ".skip_connection")
+        if skip is not None:
+            if e.updown is not None:
+                raise RuntimeError("up/down ResBlock with a channel change is not in the reference")
+            self.conv_step(skip, srcs, y, want_stats=False)   # y = skip(x), then accumulated into
+            self.conv_step(c2, [h1], y, aff=(A2, B2), act=H.ACT_SILU, res=y, res_mode=H.RES_SAME)
+        else:
+            self.conv_step(c2, [h1], y, aff=(A2, B2), act=H.ACT_SILU, res=x0, res_mode=rm)
+        return y
+
+    # ---- execution -----------------------------------------------------------
+    def run(self, x, low_res, film_rows, film_stride, out=None):
+        H.require_device(x, "x")
+        H.require_device(low_res, "low_res")
+        st = H.stream()
+        self.first_desc.src0 = x.data_ptr()
+        self.first_desc.src1 = low_res.data_ptr()
+        fptr = film_rows.data_ptr()
+        for a in self.film_patches:
+            a[12], a[13] = fptr, film_stride
+        for dsc, off in self.bias_patches:
+            dsc.bias = fptr + 4 * off
+            dsc.bias_stride_n = film_stride
+        target = out if out is not None else self.out_buf
+        self.last_desc.out = target.data_ptr()
+        for fn, args in self.steps:
+            args[-1] = st
+            rc = fn(*args)
+            if rc != 0:
+                H.check(rc)
+        if out is not None:
+            return out
+        return self.out_buf

@@ -1,0 +1,289 @@
+"""
+The reference's UNet family (unet.py:396-1044, :1655-1694) as parameter
+containers whose forward pass is a compiled HIP launch plan (engine.py).
+
+What is kept from the reference so that this is a drop-in:
+  * class names and constructor signatures (UNetModel, UNetModel_noatt,
+    SuperResModel, SuperResModel_noatt),
+  * the state_dict key scheme (time_embed.{0,2}, input_blocks.K.J.in_layers.{0,2},
+    emb_layers.1, out_layers.{0,3}, skip_connection, middle_block.J,
+    output_blocks.K.J, out.{0,2}) so reference checkpoints load unchanged,
+  * initialisation semantics (torch defaults + zeroed second conv / proj_out /
+    final conv, nn.py:68-74),
+  * forward(x, timesteps, low_res=...) -> (N, out_channels, D, H, W),
+    convert_to_fp16 / convert_to_fp32, .dtype.
+
+What is different: no module here computes anything with ATen.  The layer
+list is flattened into `Topology`, and `forward` hands x to UNetEngine.
+"""
+
+import warnings
+from collections import namedtuple
+
+import torch
+import torch.nn as nn
+
+from . import _hip as H
+from .engine import UNetEngine
+
+Layer = namedtuple("Layer", "prefix kind cin cout updown heads")
+
+
+class Topology:
+    """Flat description of the network: which layers exist, their state_dict
+    prefixes and channel widths.  Mirrors the bookkeeping of the reference
+    constructor (unet.py:805-991), including the decoder's pop-pop-push
+    width rule (unet.py:947-951, :990)."""
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 channel_mult, num_heads, num_head_channels, num_heads_upsample, resblock_updown,
+                 mid_attention):
+        def nheads(ch, n):
+            return n if num_head_channels == -1 else ch // num_head_channels
+
+        ch = int(channel_mult[0] * model_channels)
+        self.input = [[Layer("input_blocks.0.0", "conv", in_channels, ch, None, 0)]]
+        widths = [ch]
+        ds = 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                k = len(self.input)
+                co = int(mult * model_channels)
+                blk = [Layer("input_blocks.%d.0" % k, "res", ch, co, None, 0)]
+                ch = co
+                if ds in attention_resolutions:
+                    blk.append(Layer("input_blocks.%d.1" % k, "attn", ch, ch, None, nheads(ch, num_heads)))
+                self.input.append(blk)
+                widths.append(ch)
+            if level != len(channel_mult) - 1:
+                k = len(self.input)
+                kind = ("res", "down") if resblock_updown else ("downconv", None)
+                self.input.append([Layer("input_blocks.%d.0" % k, kind[0], ch, ch, kind[1], 0)])
+                widths.append(ch)
+                ds *= 2
+        self.middle = [Layer("middle_block.0", "res", ch, ch, None, 0)]
+        if mid_attention:
+            self.middle.append(Layer("middle_block.1", "attn", ch, ch, None, nheads(ch, num_heads)))
+            self.middle.append(Layer("middle_block.2", "res", ch, ch, None, 0))
+        else:
+            self.middle.append(Layer("middle_block.1", "res", ch, ch, None, 0))
+        self.output = []
+        outch = ch
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                inch = widths.pop()
+                outch = widths.pop() if widths else inch
+                k = len(self.output)
+                blk = [Layer("output_blocks.%d.0" % k, "res", 2 * inch, outch, None, 0)]
+                if ds in attention_resolutions:
+                    blk.append(Layer("output_blocks.%d.%d" % (k, len(blk)), "attn", outch, outch, None,
+                                     nheads(outch, num_heads_upsample)))
+                if level and i == num_res_blocks:
+                    kind = ("res", "up") if resblock_updown else ("upconv", None)
+                    blk.append(Layer("output_blocks.%d.%d" % (k, len(blk)), kind[0], outch, outch, kind[1], 0))
+                    ds //= 2
+                self.output.append(blk)
+                widths.append(outch)
+        self.final_ch = outch
+        self.input_ch = int(channel_mult[0] * model_channels)
+        self.out_channels = out_channels
+
+    def all_layers(self):
+        for blk in self.input:
+            yield from blk
+        yield from self.middle
+        for blk in self.output:
+            yield from blk
+
+
+# ---------------------------------------------------------------- containers
+class GroupNorm32(nn.GroupNorm):
+    """32-group norm parameters (nn.py:17-19); applied inside the conv prologue."""
+
+
+def _zero(m):
+    for p in m.parameters():
+        p.detach().zero_()
+    return m
+
+
+class ResBlock(nn.Module):
+    """Parameters of one residual block (unet.py:143-256)."""
+
+    def __init__(self, channels, emb_channels, out_channels, use_scale_shift_norm):
+        super().__init__()
+        self.in_layers = nn.Sequential(GroupNorm32(32, channels), nn.SiLU(),
+                                       nn.Conv3d(channels, out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(
+            nn.SiLU(), nn.Linear(emb_channels, 2 * out_channels if use_scale_shift_norm else out_channels))
+        self.out_layers = nn.Sequential(GroupNorm32(32, out_channels), nn.SiLU(), nn.Dropout(p=0.0),
+                                        _zero(nn.Conv3d(out_channels, out_channels, 3, padding=1)))
+        self.skip_connection = (nn.Identity() if out_channels == channels
+                                else nn.Conv3d(channels, out_channels, 1))
+
+
+class AttentionBlock(nn.Module):
+    """Parameters of one attention block (unet.py:259-305)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.norm = GroupNorm32(32, channels)
+        self.qkv = nn.Conv1d(channels, 3 * channels, 1)
+        self.proj_out = _zero(nn.Conv1d(channels, channels, 1))
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.op = nn.Conv3d(channels, channels, 3, stride=(1, 2, 2), padding=1)
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv3d(channels, channels, 3, padding=1)
+
+
+class _Block(nn.Sequential):
+    """A TimestepEmbedSequential-shaped holder (indices are state_dict key parts)."""
+
+
+def _container(layer, ted, film):
+    if layer.kind == "conv":
+        return nn.Conv3d(layer.cin, layer.cout, 3, padding=1)
+    if layer.kind == "res":
+        return ResBlock(layer.cin, ted, layer.cout, film)
+    if layer.kind == "attn":
+        return AttentionBlock(layer.cin)
+    if layer.kind == "downconv":
+        return Downsample(layer.cin)
+    if layer.kind == "upconv":
+        return Upsample(layer.cin)
+    raise ValueError(layer.kind)
+
+
+class UNetModel_noatt(nn.Module):
+    """unet.py:720-1044 (the class scripts/test.py actually builds, via
+    SuperResModel_noatt): no attention in the middle block."""
+
+    MID_ATTENTION = False
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks,
+                 attention_resolutions, dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2,
+                 num_classes=None, use_checkpoint=False, use_fp16=False, num_heads=1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 use_new_attention_order=False):
+        super().__init__()
+        if dims != 3:
+            raise NotImplementedError("the HIP engine implements the 3-D model (dims=3) only")
+        if num_classes is not None:
+            raise NotImplementedError("class conditioning is unused by the 3-D PET model")
+        if dropout:
+            raise NotImplementedError("dropout is a training-time feature; sampling uses p=0")
+        if not conv_resample and not resblock_updown:
+            raise NotImplementedError("conv_resample=False")
+        if use_new_attention_order:
+            raise NotImplementedError("use_new_attention_order is unreachable from the SR factory")
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = attention_resolutions
+        self.dropout = dropout
+        self.channel_mult = channel_mult
+        self.conv_resample = conv_resample
+        self.num_classes = num_classes
+        self.use_checkpoint = use_checkpoint
+        self.dtype = torch.float16 if use_fp16 else torch.float32
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.num_heads_upsample = num_heads_upsample
+        self.use_scale_shift_norm = use_scale_shift_norm
+        self.resblock_updown = resblock_updown
+        self.use_fp16 = use_fp16
+        self.dims = dims
+
+        self.topology = Topology(in_channels, model_channels, out_channels, num_res_blocks,
+                                 tuple(attention_resolutions), tuple(channel_mult), num_heads,
+                                 num_head_channels, num_heads_upsample, resblock_updown, self.MID_ATTENTION)
+        ted = 4 * model_channels
+        t = self.topology
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+        self.input_blocks = nn.ModuleList(
+            [_Block(*[_container(l, ted, use_scale_shift_norm) for l in blk]) for blk in t.input])
+        self.middle_block = _Block(*[_container(l, ted, use_scale_shift_norm) for l in t.middle])
+        self.output_blocks = nn.ModuleList(
+            [_Block(*[_container(l, ted, use_scale_shift_norm) for l in blk]) for blk in t.output])
+        self.out = nn.Sequential(GroupNorm32(32, t.final_ch), nn.SiLU(),
+                                 _zero(nn.Conv3d(t.input_ch, out_channels, 3, padding=1)))
+        self._engine = None
+        self._engine_key = None
+
+    # ---- precision switches (unet.py:999-1013) -------------------------------
+    def convert_to_fp16(self):
+        warnings.warn("convert_to_fp16(): the HIP engine currently computes the torso in fp32 "
+                      "(a superset of the reference's fp16 precision); parameters are left in fp32")
+        self.dtype = torch.float16
+
+    def convert_to_fp32(self):
+        self.dtype = torch.float32
+
+    # ---- engine management ----------------------------------------------------
+    def _params_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def engine(self):
+        p0 = next(self.parameters())
+        if not p0.is_cuda:
+            raise RuntimeError("model parameters are on %s: move the model to the GPU (model.to('cuda')); "
+                               "this package has no CPU path" % p0.device)
+        key = self._params_key()
+        if self._engine is None or self._engine_key != key:
+            params = {k: v.detach().float().contiguous() for k, v in self.state_dict().items()}
+            with torch.cuda.device(p0.device):
+                self._engine = UNetEngine(self.topology, params, self.model_channels,
+                                          self.use_scale_shift_norm, p0.device)
+            self._engine_key = key
+        return self._engine
+
+    def forward(self, x, timesteps, y=None, low_res=None):
+        """x: (N, in_channels_x, D, H, W) with low_res supplying the second channel."""
+        assert y is None, "must specify y if and only if the model is class-conditional"
+        if low_res is None:
+            raise RuntimeError("the 3-D model is conditional: pass low_res=... (unet.py:1687)")
+        H.require_device(x, "x")
+        eng = self.engine()
+        with torch.cuda.device(x.device):
+            rows = eng.film_rows(timesteps.to(device=x.device, dtype=torch.float32).contiguous())
+            out = eng.forward(x, low_res.to(x.device).contiguous(), rows, eng.film_total)
+            return out.clone()
+
+
+class UNetModel(UNetModel_noatt):
+    """unet.py:396-716: the same network with an AttentionBlock between the two
+    middle ResBlocks."""
+    MID_ATTENTION = True
+
+
+class SuperResModel_noatt(UNetModel_noatt):
+    """unet.py:1676-1694: conditions on `low_res` by channel concatenation (the
+    concat itself is virtual: the first conv reads the two volumes directly)."""
+
+    def __init__(self, image_size, in_channels, *args, **kwargs):
+        super().__init__(image_size, int(in_channels * 2), *args, **kwargs)
+
+    def forward(self, x, timesteps, low_res=None, **kwargs):
+        return super().forward(x, timesteps, low_res=low_res, **kwargs)
+
+
+class SuperResModel(UNetModel):
+    """unet.py:1655-1673."""
+
+    def __init__(self, image_size, in_channels, *args, **kwargs):
+        super().__init__(image_size, int(in_channels * 2), *args, **kwargs)
+
+    def forward(self, x, timesteps, low_res=None, **kwargs):
+        return super().forward(x, timesteps, low_res=low_res, **kwargs)

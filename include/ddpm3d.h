@@ -1,0 +1,197 @@
+/*
+ * ddpm3d -- C ABI of the MI355X-native 3-D DDPM denoising sampler.
+ *
+ * The reference (Zachary-Luk/3D-Denoising-Diffusion-Model) has no FFI, plugin
+ * or operator interface: its hot path is plain Python calling ATen.  The
+ * entry points below are therefore what a binding for that path binds --
+ * one per ATen-op family the path issues -- and each
+ * one cites the reference lines whose arithmetic it replaces.  The Python
+ * mirror of the reference API (3d-denoising-diffusion-model_amd/
+ * guided_diffusion/) reaches them through ctypes; INTEGRATION.md shows the
+ * stub.
+ *
+ * Conventions
+ *   - Plain C: pointers are DEVICE pointers (hipMalloc / torch caching
+ *     allocator), sizes are ints, `stream` is a hipStream_t passed as void*.
+ *   - Every call only ENQUEUES work on `stream` (no allocation, no
+ *     synchronisation, graph-capturable).  The caller owns every buffer and
+ *     keeps it alive until the stream has passed the call.
+ *   - Return 0 on success, a negative DDPM3D_E* code otherwise;
+ *     ddpm3d_last_error() gives a thread-local message.  No C++ exception
+ *     crosses the boundary.
+ *   - Activations are channels-last fp32: [N][D][H][W][C] ("NDHWC").  The
+ *     reference's NCDHW tensors are converted at the API edge only
+ *     (ddpm3d_ncdhw_to_ndhwc / the planar input mode of the first conv /
+ *     the NCDHW store mode of the last conv).
+ *   - GroupNorm is never a pass of its own: every conv epilogue emits
+ *     per-(sample, row-tile, channel) partial sums (sum, sum of squares) of
+ *     what it stores; ddpm3d_gn_finalize folds them (fp64) into per-(n, c)
+ *     affine coefficients A, B; the NEXT conv applies
+ *     y = SiLU(A*x + B) while it stages its input tile into LDS.
+ */
+#ifndef DDPM3D_H
+#define DDPM3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDPM3D_ABI_VERSION 1
+
+enum {
+    DDPM3D_OK = 0,
+    DDPM3D_EINVAL = -1,   /* bad descriptor (shape / alignment / mode)        */
+    DDPM3D_ELAUNCH = -2,  /* HIP refused the launch                           */
+    DDPM3D_ENOSUP = -3    /* valid request the library does not implement    */
+};
+
+/* input staging modes of ddpm3d_conv3d (where the conv's input voxel (z,y,x)
+ * is read from) */
+enum {
+    DDPM3D_IN_SAME = 0,    /* source has the conv's D,H,W                              */
+    DDPM3D_IN_POOL = 1,    /* source is D,2H,2W; input = mean of the 2x2 (H,W) window
+                              of act(A*x+B)  -- Downsample, unet.py:129-136, applied
+                              after norm+act and before the conv, unet.py:237-242      */
+    DDPM3D_IN_UP = 2,      /* source is D,H/2,W/2; nearest (y>>1, x>>1) -- Upsample,
+                              unet.py:102-105                                          */
+    DDPM3D_IN_PLANAR2 = 3  /* src0, src1 are two single-channel NCDHW volumes (x and
+                              low_res, unet.py:1690-1693); Cin = 2                     */
+};
+
+/* residual modes of the conv epilogue (out = conv + bias + residual) */
+enum {
+    DDPM3D_RES_NONE = 0,
+    DDPM3D_RES_SAME = 1,   /* skip(x) + h with x at the output resolution, unet.py:256 */
+    DDPM3D_RES_POOL = 2,   /* x_upd = Downsample(x), unet.py:241                       */
+    DDPM3D_RES_UP = 3      /* x_upd = Upsample(x),   unet.py:241                       */
+};
+
+enum { DDPM3D_ACT_NONE = 0, DDPM3D_ACT_SILU = 1 };
+enum { DDPM3D_OUT_NDHWC = 0, DDPM3D_OUT_NCDHW = 1 };
+
+/*
+ * 3x3x3 (pad 1, stride 1) or 1x1x1 convolution as an implicit GEMM on the
+ * matrix cores, with everything element-wise around it fused in.
+ * Replaces, per call: nn.Conv3d (nn.py:22-32; unet.py:185,211,222,810,996),
+ * the preceding GroupNorm32-apply + SiLU (+ FiLM) (nn.py:93-100,
+ * unet.py:183-184,207-208,248-252), AvgPool3d / nearest Upsample
+ * (unet.py:102-105,129-136), th.cat of the skip (unet.py:1041), the residual
+ * add (unet.py:256) and the statistics pass of the FOLLOWING GroupNorm.
+ */
+typedef struct ddpm3d_conv_desc {
+    /* geometry of the convolution's OUTPUT grid */
+    int32_t N, D, H, W;
+    int32_t Cin;            /* = C0 + C1                                             */
+    int32_t Cout;
+    int32_t ksize;          /* 3 or 1                                                */
+    int32_t in_mode;        /* DDPM3D_IN_*                                           */
+    /* virtual concat along C: channels [0,C0) from src0, [C0,Cin) from src1 */
+    const float* src0;
+    const float* src1;      /* NULL when C1 == 0                                     */
+    int32_t C0, C1;
+    /* prologue y = act(A[n][c]*x + B[n][c]); aff_a == NULL -> y = x */
+    const float* aff_a;     /* [N][Cin]                                              */
+    const float* aff_b;     /* [N][Cin]                                              */
+    int32_t act;            /* DDPM3D_ACT_*                                          */
+    int32_t precision;      /* 0 = exact fp32 MFMA; others reserved                  */
+    /* weights in the layout ddpm3d_pack_conv_weight produces; bias [Cout]
+     * (bias_stride_n = 0), or one row of Cout values per sample, rows
+     * bias_stride_n floats apart (additive timestep embedding, unet.py:254-255) */
+    const float* w_packed;
+    const float* bias;
+    int32_t bias_stride_n;
+    int32_t res_mode;       /* DDPM3D_RES_*                                          */
+    const float* res;       /* [N][..][Cout] NDHWC at the resolution res_mode implies */
+    float* out;
+    int32_t out_layout;     /* DDPM3D_OUT_*                                          */
+    int32_t stats_rows;     /* rows per sample of `stats` (from ddpm3d_conv_stats_rows) */
+    float* stats;           /* [N][stats_rows][Cout][2] or NULL                      */
+} ddpm3d_conv_desc;
+
+int ddpm3d_abi_version(void);
+const char* ddpm3d_last_error(void);
+
+/* number of fp32 elements of the packed form of an (Cout, Cin, k, k, k) weight */
+size_t ddpm3d_packed_weight_elems(int Cout, int Cin, int ksize);
+/* OIDHW (torch Conv3d.weight / Conv1d.weight with k=1) -> packed; device to device */
+int ddpm3d_pack_conv_weight(const float* w_oidhw, int Cout, int Cin, int ksize,
+                            float* w_packed, void* stream);
+
+/* rows per sample of the statistics buffer a conv over (D,H,W) with Cout
+ * outputs writes */
+int ddpm3d_conv_stats_rows(int D, int H, int W, int Cout, int ksize);
+int ddpm3d_conv3d(const ddpm3d_conv_desc* desc, void* stream);
+
+/*
+ * GroupNorm32 statistics -> affine coefficients (nn.py:93-100: 32 groups,
+ * eps 1e-5, affine gamma/beta), optionally composed with FiLM
+ * h*(1+scale)+shift (unet.py:248-252).  The normalised tensor is the virtual
+ * concat of up to two tensors with partial sums stats0 [N][rows0][C0][2] and
+ * stats1 [N][rows1][C1][2]; `count` = voxels per channel.
+ *   A[n][c] = rstd*gamma[c]*(1+scale[n][c]);
+ *   B[n][c] = (beta[c]-mean*rstd*gamma[c])*(1+scale[n][c]) + shift[n][c]
+ * film = [N][film_stride] rows holding scale at [film_off, +C) and shift at
+ * [film_off + C, +C); NULL -> no FiLM.
+ */
+int ddpm3d_gn_finalize(const float* stats0, int C0, int rows0,
+                       const float* stats1, int C1, int rows1,
+                       int N, int groups, double count, float eps,
+                       const float* gamma, const float* beta,
+                       const float* film, int film_stride, int film_off,
+                       float* aff_a, float* aff_b, void* stream);
+
+/* partial sums of an NDHWC tensor that no conv epilogue produced;
+ * stats [N][rows][C][2] with rows = ddpm3d_gn_stats_rows(voxels) */
+int ddpm3d_gn_stats_rows(int voxels);
+int ddpm3d_gn_stats(const float* x, int N, int voxels, int C, float* stats, void* stream);
+
+/* nn.py:103-121 timestep_embedding: out[r] = [cos(t_r f) | sin(t_r f)] (+0 pad) */
+int ddpm3d_timestep_embedding(const float* t, int rows, int dim, float max_period,
+                              float* out, void* stream);
+/* nn.Linear (time_embed unet.py:799-803, emb_layers unet.py:199-205):
+ * out[r][o] = bias[o] + sum_k f(in[r][k]) * w[o][k],  f = SiLU if silu_in */
+int ddpm3d_linear(const float* in, int rows, int K, const float* w, const float* bias,
+                  int O, int silu_in, float* out, int out_stride, void* stream);
+
+/* layout changes at the API edge */
+int ddpm3d_ncdhw_to_ndhwc(const float* in, int N, int C, int voxels, float* out, void* stream);
+int ddpm3d_ndhwc_to_ncdhw(const float* in, int N, int C, int voxels, float* out, void* stream);
+
+/*
+ * One reverse-diffusion update for a batch (everything after the network call):
+ * gaussian_diffusion.py:262-326 (p_mean_variance), :430-438 (p_sample) and
+ * :566-584 (ddim_sample).  coef = [T][DDPM3D_NCOEF] fp32 table (fp64-computed,
+ * fp32-applied like _extract_into_tensor, :897-910); t_idx[n] selects the row.
+ * model_out is NCDHW (N, 2 or 1, voxels); x, noise, sample, pred_xstart are
+ * (N, 1, voxels).  pred_xstart may be NULL.
+ */
+enum {
+    DDPM3D_C_SQRT_RECIP_ACP = 0,
+    DDPM3D_C_SQRT_RECIPM1_ACP = 1,
+    DDPM3D_C_POST_MEAN_COEF1 = 2,
+    DDPM3D_C_POST_MEAN_COEF2 = 3,
+    DDPM3D_C_MIN_LOG = 4,       /* posterior_log_variance_clipped; FIXED_*: the fixed log-variance */
+    DDPM3D_C_MAX_LOG = 5,       /* log(betas)                                                      */
+    DDPM3D_C_ACP = 6,
+    DDPM3D_C_ACP_PREV = 7,
+    DDPM3D_NCOEF = 8
+};
+enum {
+    DDPM3D_F_LEARN_SIGMA = 1,   /* ModelVarType.LEARNED_RANGE (model_out has 2 channels) */
+    DDPM3D_F_PREDICT_XSTART = 2,
+    DDPM3D_F_CLIP = 4
+};
+int ddpm3d_p_sample_step(const float* model_out, const float* x, const float* noise,
+                         const float* coef, const int64_t* t_idx, int N, int voxels,
+                         int flags, float* sample, float* pred_xstart, void* stream);
+int ddpm3d_ddim_step(const float* model_out, const float* x, const float* noise,
+                     const float* coef, const int64_t* t_idx, int N, int voxels,
+                     int flags, float eta, float* sample, float* pred_xstart, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDPM3D_H */

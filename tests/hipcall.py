@@ -1,0 +1,95 @@
+"""Thin test helpers that call the C ABI (include/ddpm3d.h) on torch device tensors."""
+
+import ctypes as C
+
+import torch
+
+from guided_diffusion import _hip as H
+
+
+def to_ndhwc(x):
+    """(N,C,D,H,W) -> contiguous (N,D,H,W,C)"""
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def to_ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def pack(w):
+    lib = H.load()
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    out = torch.empty(lib.ddpm3d_packed_weight_elems(co, ci, k), dtype=torch.float32, device=w.device)
+    H.check(lib.ddpm3d_pack_conv_weight(H.ptr(w.contiguous()), co, ci, k, H.ptr(out), H.stream()))
+    return out
+
+
+def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res=None, res_mode=H.RES_NONE,
+           out_layout=H.OUT_NDHWC, want_stats=True, planar=False, bias_stride_n=0):
+    """srcs: list of NDHWC device tensors (or two (N,1,D,H,W) volumes when planar).
+    Returns (out, stats, rows)."""
+    lib = H.load()
+    dev = w.device
+    co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+    N = srcs[0].shape[0]
+    D, Hh, W = out_dhw
+    d = H.ConvDesc()
+    d.N, d.D, d.H, d.W, d.Cout, d.ksize = N, D, Hh, W, co, k
+    if planar:
+        d.in_mode, d.Cin, d.C0, d.C1 = H.IN_PLANAR2, 2, 1, 1
+        d.src0, d.src1 = H.ptr(srcs[0]), H.ptr(srcs[1])
+    else:
+        d.in_mode = in_mode
+        d.src0, d.C0 = H.ptr(srcs[0]), srcs[0].shape[-1]
+        if len(srcs) > 1:
+            d.src1, d.C1 = H.ptr(srcs[1]), srcs[1].shape[-1]
+        d.Cin = d.C0 + d.C1
+    assert d.Cin == ci
+    if aff is not None:
+        d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
+    d.act = act
+    wp = pack(w)
+    d.w_packed, d.bias, d.bias_stride_n = H.ptr(wp), H.ptr(b), bias_stride_n
+    d.res_mode, d.res = res_mode, H.ptr(res)
+    if out_layout == H.OUT_NDHWC:
+        out = torch.full((N, D, Hh, W, co), float("nan"), dtype=torch.float32, device=dev)
+    else:
+        out = torch.full((N, co, D, Hh, W), float("nan"), dtype=torch.float32, device=dev)
+    d.out, d.out_layout = H.ptr(out), out_layout
+    rows = lib.ddpm3d_conv_stats_rows(D, Hh, W, co, k)
+    stats = None
+    if want_stats and out_layout == H.OUT_NDHWC:
+        stats = torch.full((N, rows, co, 2), float("nan"), dtype=torch.float32, device=dev)
+        d.stats, d.stats_rows = H.ptr(stats), rows
+    H.check(lib.ddpm3d_conv3d(C.byref(d), H.stream()))
+    torch.cuda.synchronize()
+    return out, stats, rows
+
+
+def gn_finalize(stats_list, count, gamma, beta, film=None, film_stride=0, film_off=0, groups=32):
+    lib = H.load()
+    s0 = stats_list[0]
+    s1 = stats_list[1] if len(stats_list) > 1 else None
+    N = s0.shape[0]
+    Cn = s0.shape[2] + (s1.shape[2] if s1 is not None else 0)
+    A = torch.empty(N, Cn, dtype=torch.float32, device=s0.device)
+    B = torch.empty(N, Cn, dtype=torch.float32, device=s0.device)
+    H.check(lib.ddpm3d_gn_finalize(H.ptr(s0), s0.shape[2], s0.shape[1],
+                                   H.ptr(s1), s1.shape[2] if s1 is not None else 0,
+                                   s1.shape[1] if s1 is not None else 0,
+                                   N, groups, float(count), 1e-5, H.ptr(gamma), H.ptr(beta),
+                                   H.ptr(film), film_stride, film_off, H.ptr(A), H.ptr(B), H.stream()))
+    torch.cuda.synchronize()
+    return A, B
+
+
+def gn_stats(x_ndhwc):
+    lib = H.load()
+    N = x_ndhwc.shape[0]
+    Cn = x_ndhwc.shape[-1]
+    vox = x_ndhwc[0].numel() // Cn
+    rows = lib.ddpm3d_gn_stats_rows(vox)
+    st = torch.full((N, rows, Cn, 2), float("nan"), dtype=torch.float32, device=x_ndhwc.device)
+    H.check(lib.ddpm3d_gn_stats(H.ptr(x_ndhwc), N, vox, Cn, H.ptr(st), H.stream()))
+    torch.cuda.synchronize()
+    return st

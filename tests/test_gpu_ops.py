@@ -1,0 +1,284 @@
+"""
+Per-kernel parity on the GPU, through the C ABI, against torch-CPU fp32
+functional ops (the oracle's building blocks).  Tolerance: the fp32 MFMA is an
+exact k-ordered fmaf chain, so differences vs the CPU are summation-order
+rounding only -- 2e-5 relative to the output's max is the bar for K up to
+~7000 terms.
+"""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def hc():
+    import hipcall
+    return hipcall
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def ref_stats(y_ncdhw):
+    """(sum, sumsq) per (n, c) in fp64"""
+    y = y_ncdhw.double()
+    return y.sum(dim=(2, 3, 4)), (y * y).sum(dim=(2, 3, 4))
+
+
+def check_stats(stats, y_ncdhw):
+    s = stats.double().sum(dim=1).cpu()  # [N][C][2]
+    r1, r2 = ref_stats(y_ncdhw)
+    assert torch.allclose(s[..., 0], r1, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s[..., 1], r2, rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("N,D,Hh,W,ci,co", [
+    (1, 4, 8, 8, 16, 32),      # one tile, WN=1
+    (2, 5, 12, 9, 32, 48),     # ragged in every dim, WN=2 with a partial cout tile
+    (1, 3, 16, 16, 48, 128),   # WN=4
+    (1, 9, 4, 4, 32, 96),      # 4x4 tiles (low-resolution levels), partial D tile, idle wave
+    (1, 2, 2, 2, 16, 160),     # H,W below the tile, two cout blocks
+    (1, 2, 6, 6, 32, 64),      # 96^3-patch style non-power-of-two H,W on 4x4 tiles
+])
+def test_conv3d_k3_plain(hc, N, D, Hh, W, ci, co):
+    x = rnd(N, ci, D, Hh, W, seed=1)
+    w = rnd(co, ci, 3, 3, 3, seed=2, scale=0.05)
+    b = rnd(co, seed=3)
+    ref = F.conv3d(x, w, b, padding=1)
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (D, Hh, W))
+    got = hc.to_ncdhw(out.cpu())
+    assert rel_err(got.numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)
+
+
+def test_conv3d_exact_integer_mapping(hc):
+    """Small-integer data makes every product and sum exact: any wrong tap, channel
+    permutation or row/column swap shows up as a mismatch, not as rounding."""
+    g = np.random.default_rng(5)
+    x = torch.from_numpy(g.integers(-3, 4, (1, 16, 3, 9, 10)).astype(np.float32))
+    w = torch.from_numpy(g.integers(-2, 3, (40, 16, 3, 3, 3)).astype(np.float32))
+    b = torch.from_numpy(g.integers(-5, 6, (40,)).astype(np.float32))
+    ref = F.conv3d(x, w, b, padding=1)
+    out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (3, 9, 10))
+    assert torch.equal(hc.to_ncdhw(out.cpu()), ref)
+
+
+def test_conv3d_k1_concat(hc):
+    xa, xb = rnd(2, 32, 3, 8, 8, seed=1), rnd(2, 16, 3, 8, 8, seed=2)
+    w = rnd(64, 48, 1, 1, 1, seed=3, scale=0.1)
+    b = rnd(64, seed=4)
+    ref = F.conv3d(torch.cat([xa, xb], 1), w, b)
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(xa).cuda(), hc.to_ndhwc(xb).cuda()], w.cuda(), b.cuda(), (3, 8, 8))
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)
+
+
+def test_conv3d_planar_first_layer(hc):
+    x, lr = rnd(2, 1, 4, 10, 12, seed=1), rnd(2, 1, 4, 10, 12, seed=2)
+    w = rnd(32, 2, 3, 3, 3, seed=3, scale=0.2)
+    b = rnd(32, seed=4)
+    ref = F.conv3d(torch.cat([x, lr], 1), w, b, padding=1)
+    out, _, _ = hc.conv3d([x.cuda(), lr.cuda()], w.cuda(), b.cuda(), (4, 10, 12), planar=True)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+
+
+def test_conv3d_ncdhw_store_small_cout(hc):
+    x = rnd(1, 32, 4, 8, 8, seed=1)
+    w = rnd(2, 32, 3, 3, 3, seed=2, scale=0.05)
+    b = rnd(2, seed=3)
+    ref = F.conv3d(x, w, b, padding=1)
+    import guided_diffusion._hip as H
+    out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (4, 8, 8), out_layout=H.OUT_NCDHW)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < TOL
+
+
+def _gn_affine(hc, x_list, gamma, beta, film=None):
+    """A, B from the stand-alone statistics kernel + finalize."""
+    stats = [hc.gn_stats(hc.to_ndhwc(x).cuda()) for x in x_list]
+    vox = x_list[0][0, 0].numel()
+    if film is not None:
+        return hc.gn_finalize(stats, vox, gamma.cuda(), beta.cuda(), film.cuda(), film.shape[1], 0)
+    return hc.gn_finalize(stats, vox, gamma.cuda(), beta.cuda())
+
+
+@pytest.mark.parametrize("C0,C1", [(32, 0), (64, 64), (96, 0), (32, 32)])
+def test_groupnorm_silu_prologue(hc, C0, C1):
+    """GN32 (+concat) + SiLU fused into a 1x1x1 identity conv == F.silu(F.group_norm(cat))."""
+    import guided_diffusion._hip as H
+    xs = [rnd(2, C0, 3, 8, 8, seed=1) * 2 + 0.5]
+    if C1:
+        xs.append(rnd(2, C1, 3, 8, 8, seed=2) * 0.7 - 1.0)
+    Cn = C0 + C1
+    gamma, beta = 1 + 0.1 * rnd(Cn, seed=3), 0.1 * rnd(Cn, seed=4)
+    ref = F.silu(F.group_norm(torch.cat(xs, 1), 32, gamma, beta, 1e-5))
+    A, B = _gn_affine(hc, xs, gamma, beta)
+    w = torch.eye(Cn).reshape(Cn, Cn, 1, 1, 1).contiguous()
+    out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda() for x in xs], w.cuda(), torch.zeros(Cn).cuda(), (3, 8, 8),
+                          aff=(A, B), act=H.ACT_SILU)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < 1e-5
+
+
+def test_groupnorm_film(hc):
+    """out_norm(h) * (1 + scale) + shift then SiLU (unet.py:248-252)."""
+    import guided_diffusion._hip as H
+    x = rnd(2, 64, 2, 8, 8, seed=1)
+    gamma, beta = 1 + 0.1 * rnd(64, seed=3), 0.1 * rnd(64, seed=4)
+    film = rnd(2, 128, seed=5, scale=0.5)
+    scale, shift = film[:, :64, None, None, None], film[:, 64:, None, None, None]
+    ref = F.silu(F.group_norm(x, 32, gamma, beta, 1e-5) * (1 + scale) + shift)
+    A, B = _gn_affine(hc, [x], gamma, beta, film)
+    w = torch.eye(64).reshape(64, 64, 1, 1, 1).contiguous()
+    out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), torch.zeros(64).cuda(), (2, 8, 8),
+                          aff=(A, B), act=H.ACT_SILU)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < 1e-5
+
+
+def test_conv_stats_feed_groupnorm(hc):
+    """Statistics from a conv epilogue, folded, reproduce group_norm of its output."""
+    x = rnd(1, 32, 5, 12, 12, seed=1)
+    w = rnd(64, 32, 3, 3, 3, seed=2, scale=0.05)
+    b = rnd(64, seed=3)
+    y = F.conv3d(x, w, b, padding=1)
+    gamma, beta = 1 + 0.1 * rnd(64, seed=4), 0.1 * rnd(64, seed=5)
+    ref = F.group_norm(y, 32, gamma, beta, 1e-5)
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (5, 12, 12))
+    A, B = hc.gn_finalize([stats], 5 * 12 * 12, gamma.cuda(), beta.cuda())
+    got = hc.to_ncdhw(out.cpu()) * A.cpu()[:, :, None, None, None] + B.cpu()[:, :, None, None, None]
+    assert rel_err(got.numpy(), ref.numpy()) < 1e-5
+
+
+def test_conv3d_downsample_block_paths(hc):
+    """conv(avgpool(SiLU(GN(x)))) + avgpool(x): the `down` ResBlock's two pooled paths."""
+    import guided_diffusion._hip as H
+    x = rnd(1, 32, 3, 16, 12, seed=1)
+    gamma, beta = 1 + 0.1 * rnd(32, seed=3), 0.1 * rnd(32, seed=4)
+    w = rnd(32, 32, 3, 3, 3, seed=2, scale=0.05)
+    b = rnd(32, seed=5)
+    pool = lambda t: F.avg_pool3d(t, (1, 2, 2), (1, 2, 2))
+    ref = F.conv3d(pool(F.silu(F.group_norm(x, 32, gamma, beta, 1e-5))), w, b, padding=1) + pool(x)
+    xd = hc.to_ndhwc(x).cuda()
+    A, B = _gn_affine(hc, [x], gamma, beta)
+    out, stats, _ = hc.conv3d([xd], w.cuda(), b.cuda(), (3, 8, 6), in_mode=H.IN_POOL, aff=(A, B),
+                              act=H.ACT_SILU, res=xd, res_mode=H.RES_POOL)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)
+
+
+def test_conv3d_upsample_block_paths(hc):
+    import guided_diffusion._hip as H
+    x = rnd(1, 32, 3, 4, 6, seed=1)
+    gamma, beta = 1 + 0.1 * rnd(32, seed=3), 0.1 * rnd(32, seed=4)
+    w = rnd(32, 32, 3, 3, 3, seed=2, scale=0.05)
+    b = rnd(32, seed=5)
+    up = lambda t: F.interpolate(t, (t.shape[2], t.shape[3] * 2, t.shape[4] * 2), mode="nearest")
+    ref = F.conv3d(up(F.silu(F.group_norm(x, 32, gamma, beta, 1e-5))), w, b, padding=1) + up(x)
+    xd = hc.to_ndhwc(x).cuda()
+    A, B = _gn_affine(hc, [x], gamma, beta)
+    out, _, _ = hc.conv3d([xd], w.cuda(), b.cuda(), (3, 8, 12), in_mode=H.IN_UP, aff=(A, B),
+                          act=H.ACT_SILU, res=xd, res_mode=H.RES_UP)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+
+
+def test_conv3d_residual_in_place(hc):
+    """out = conv(h) + out (the 1x1 skip result already sitting in the output buffer)."""
+    import ctypes as C
+    import guided_diffusion._hip as H
+    h = rnd(1, 32, 2, 8, 8, seed=1)
+    r = rnd(1, 48, 2, 8, 8, seed=2)
+    w = rnd(48, 32, 3, 3, 3, seed=3, scale=0.05)
+    b = rnd(48, seed=4)
+    ref = F.conv3d(h, w, b, padding=1) + r
+    buf = hc.to_ndhwc(r).cuda()
+    lib = H.load()
+    d = H.ConvDesc()
+    d.N, d.D, d.H, d.W, d.Cin, d.Cout, d.ksize, d.in_mode = 1, 2, 8, 8, 32, 48, 3, H.IN_SAME
+    hd = hc.to_ndhwc(h).cuda()
+    wp, bd = hc.pack(w.cuda()), b.cuda()
+    d.src0, d.C0, d.w_packed, d.bias = H.ptr(hd), 32, H.ptr(wp), H.ptr(bd)
+    d.res_mode, d.res, d.out = H.RES_SAME, H.ptr(buf), H.ptr(buf)
+    H.check(lib.ddpm3d_conv3d(C.byref(d), H.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(hc.to_ncdhw(buf.cpu()).numpy(), ref.numpy()) < TOL
+
+
+def test_conv3d_rejects_bad_descriptors(hc):
+    import ctypes as C
+    import guided_diffusion._hip as H
+    lib = H.load()
+    d = H.ConvDesc()
+    assert lib.ddpm3d_conv3d(C.byref(d), 0) == -1          # all-zero descriptor
+    assert b"shape" in lib.ddpm3d_last_error()
+    x = torch.zeros(1, 2, 8, 8, 24, device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        hc.conv3d([x], torch.zeros(32, 24, 3, 3, 3, device="cuda"), torch.zeros(32, device="cuda"), (2, 8, 8))
+
+
+def test_linear_and_timestep_embedding(hc):
+    import guided_diffusion._hip as H
+    lib = H.load()
+    t = torch.tensor([0.0, 4.0, 499.0, 999.0, 123.0])
+    from oracle import unet_ref
+    ref = unet_ref.timestep_embedding(t, 128)
+    td, out = t.cuda(), torch.empty(5, 128, device="cuda")
+    H.check(lib.ddpm3d_timestep_embedding(H.ptr(td), 5, 128, 10000.0, H.ptr(out), H.stream()))
+    assert torch.allclose(out.cpu(), ref, atol=2e-6, rtol=0)
+    for rows, K, O, silu in [(5, 128, 512, 0), (11, 512, 70, 1), (1, 96, 3, 1)]:
+        x, w, b = rnd(rows, K, seed=1), rnd(O, K, seed=2, scale=0.05), rnd(O, seed=3)
+        ref = F.linear(F.silu(x) if silu else x, w, b)
+        o = torch.empty(rows, O, device="cuda")
+        H.check(lib.ddpm3d_linear(H.ptr(x.cuda()), rows, K, H.ptr(w.cuda()), H.ptr(b.cuda()), O, silu,
+                                  H.ptr(o), O, H.stream()))
+        assert rel_err(o.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_layout_round_trip(hc):
+    import guided_diffusion._hip as H
+    lib = H.load()
+    x = rnd(2, 37, 3, 5, 7, seed=1)
+    xd = x.cuda()
+    y = torch.empty(2, 3, 5, 7, 37, device="cuda")
+    H.check(lib.ddpm3d_ncdhw_to_ndhwc(H.ptr(xd), 2, 37, 105, H.ptr(y), H.stream()))
+    assert torch.equal(y.cpu(), hc.to_ndhwc(x))
+    z = torch.empty_like(xd)
+    H.check(lib.ddpm3d_ndhwc_to_ncdhw(H.ptr(y), 2, 37, 105, H.ptr(z), H.stream()))
+    assert torch.equal(z.cpu(), x)
+
+
+@pytest.mark.parametrize("learn,xstart,clip", [(True, False, True), (False, False, True),
+                                               (True, True, False), (True, False, False)])
+def test_sampler_update_kernels(hc, learn, xstart, clip):
+    import guided_diffusion._hip as H
+    from guided_diffusion import script_util as su
+    from oracle import sampler_ref, schedule_ref
+    diff = su.create_gaussian_diffusion(steps=1000, learn_sigma=learn, predict_xstart=xstart,
+                                        timestep_respacing="10")
+    _, tb = schedule_ref.spaced_schedule(1000, "linear", "10")
+    N, vox = 3, 1000
+    x, z = rnd(N, 1, 10, 10, 10, seed=1), rnd(N, 1, 10, 10, 10, seed=2)
+    mo = rnd(N, 2 if learn else 1, 10, 10, 10, seed=3)
+    for i in (9, 4, 0):
+        t = torch.full((N,), i, dtype=torch.long)
+        mean, logvar, x0 = sampler_ref.mean_variance(tb, mo, x, i, learn, xstart, clip)
+        ref = mean + (0.0 if i == 0 else 1.0) * torch.exp(0.5 * logvar) * z
+        got = diff._update("ddpm", mo.cuda(), x.cuda(), t, z.cuda(), clip)
+        assert rel_err(got["sample"].cpu().numpy(), ref.numpy()) < 2e-6
+        assert rel_err(got["pred_xstart"].cpu().numpy(), x0.numpy()) < 2e-6
+        for eta in (0.0, 0.7):
+            got2 = diff._update("ddim", mo.cuda(), x.cuda(), t, z.cuda(), clip, eta)
+            # single-step DDIM reference, written out (gaussian_diffusion.py:566-584)
+            c = lambda k: float(np.float32(tb[k][i]))
+            eps = (c("sqrt_recip_alphas_cumprod") * x - x0) / c("sqrt_recipm1_alphas_cumprod")
+            ab, abp = torch.tensor(c("alphas_cumprod")), torch.tensor(c("alphas_cumprod_prev"))
+            sig = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
+            ref2 = x0 * torch.sqrt(abp) + torch.sqrt(1 - abp - sig ** 2) * eps + (0.0 if i == 0 else 1.0) * sig * z
+            assert rel_err(got2["sample"].cpu().numpy(), ref2.numpy()) < 2e-6

@@ -1,0 +1,174 @@
+"""
+CPU tier: host-side logic of the product package (flag system, schedules,
+state_dict key scheme, topology) against the reference's golden outputs, and
+the C-ABI library's exports.  No compute call is made here (no GPU).
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from guided_diffusion import _hip
+from guided_diffusion import gaussian_diffusion as gd
+from guided_diffusion import script_util as su
+from guided_diffusion.respace import SpacedDiffusion, _WrappedModel, space_timesteps
+
+PUBLISHED = dict(large_size=96, small_size=96, num_channels=128, num_res_blocks=2, num_head_channels=64,
+                 attention_resolutions="1000", learn_sigma=True, resblock_updown=True,
+                 use_scale_shift_norm=True)
+TINY = dict(PUBLISHED, num_channels=32, num_res_blocks=1)
+TABLES = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
+          "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+          "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+          "posterior_mean_coef1", "posterior_mean_coef2"]
+
+
+def test_library_exports_every_declared_symbol():
+    """include/ddpm3d.h <-> libddpm3d.so <-> the ctypes table agree."""
+    hdr = open(os.path.join(ROOT, "include", "ddpm3d.h")).read()
+    declared = set(re.findall(r"\b(ddpm3d_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_hip.EXPORTS), declared ^ set(_hip.EXPORTS)
+    assert os.path.exists(_hip.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.ddpm3d_abi_version.restype = ctypes.c_int
+    assert lib.ddpm3d_abi_version() == _hip.ABI_VERSION
+    # pure host-side helpers are callable without a GPU
+    lib.ddpm3d_packed_weight_elems.restype = ctypes.c_size_t
+    assert lib.ddpm3d_packed_weight_elems(128, 128, 3) == 27 * 128 * 128
+    assert lib.ddpm3d_packed_weight_elems(2, 128, 3) == 27 * 128 * 32      # Cout padded to 32
+    assert lib.ddpm3d_packed_weight_elems(128, 2, 3) == 27 * 16 * 128      # Cin padded to 16
+    assert lib.ddpm3d_packed_weight_elems(8, 8, 2) == 0
+    assert lib.ddpm3d_conv_stats_rows(64, 64, 64, 128, 3) == 32 * 8 * 8
+    assert lib.ddpm3d_conv_stats_rows(64, 4, 4, 512, 3) == 8
+
+
+def test_conv_desc_struct_layout_matches_header():
+    """Field order/offsets of the ctypes mirror: 8 ints, 2 ptrs, 2 ints, 2 ptrs, 2 ints, ..."""
+    f = {n: getattr(_hip.ConvDesc, n).offset for n, _ in _hip.ConvDesc._fields_}
+    assert f["src0"] == 32 and f["C0"] == 48 and f["aff_a"] == 56 and f["act"] == 72
+    assert f["w_packed"] == 80 and f["bias_stride_n"] == 96 and f["res"] == 104 and f["out"] == 112
+    assert f["out_layout"] == 120 and f["stats"] == 128 and ctypes.sizeof(_hip.ConvDesc) == 136
+
+
+def test_sr_defaults_and_flag_parsing():
+    d = su.sr_model_and_diffusion_defaults()
+    assert list(d) == ["num_channels", "num_res_blocks", "num_heads", "num_heads_upsample",
+                       "num_head_channels", "attention_resolutions", "dropout", "class_cond",
+                       "use_checkpoint", "use_scale_shift_norm", "resblock_updown", "use_fp16",
+                       "learn_sigma", "diffusion_steps", "noise_schedule", "timestep_respacing", "use_kl",
+                       "predict_xstart", "rescale_timesteps", "rescale_learned_sigmas", "large_size",
+                       "small_size"]
+    assert d["large_size"] == 256 and d["small_size"] == 64 and d["attention_resolutions"] == "16,8"
+    assert "channel_mult" not in d and "image_size" not in d and "use_new_attention_order" not in d
+    p = argparse.ArgumentParser()
+    su.add_dict_to_argparser(p, dict(d, save_dir="", clip_denoised=True, none_flag=None))
+    a = p.parse_args("--use_fp16 True --large_size 96 --learn_sigma yes --dropout 0.1 --none_flag x".split())
+    assert a.use_fp16 is True and a.large_size == 96 and a.learn_sigma is True and a.dropout == 0.1
+    assert a.none_flag == "x" and a.clip_denoised is True
+    assert su.args_to_dict(a, ["large_size", "use_fp16"]) == {"large_size": 96, "use_fp16": True}
+    with pytest.raises(argparse.ArgumentTypeError):
+        su.str2bool("maybe")
+
+
+def test_state_dict_keys_and_init_semantics():
+    with open(os.path.join(GOLDEN, "state_keys.json")) as f:
+        ref = json.load(f)
+    cases = {"tiny": TINY, "published": PUBLISHED,
+             "tiny_attn": dict(TINY, large_size=32, attention_resolutions="8,4", num_head_channels=32),
+             "tiny_ls64": dict(TINY, large_size=64)}
+    for tag, over in cases.items():
+        fl = su.sr_model_and_diffusion_defaults()
+        fl.update(over)
+        model, _ = su.sr_create_model_and_diffusion(**fl)
+        mine = [(k, list(v.shape)) for k, v in model.state_dict().items()]
+        assert mine == [(a, b) for a, b in ref[tag]], tag
+        if tag == "published":
+            assert sum(p.numel() for p in model.parameters()) == ref["published_param_count"]
+        if tag == "tiny":
+            sd = model.state_dict()
+            # zero_module'd layers (nn.py:68-74; unet.py:210-212, :996)
+            assert float(sd["out.2.weight"].abs().max()) == 0 and float(sd["out.2.bias"].abs().max()) == 0
+            assert float(sd["input_blocks.1.0.out_layers.3.weight"].abs().max()) == 0
+            assert float(sd["input_blocks.1.0.in_layers.2.weight"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("tag,resp", [("full", ""), ("250", "250"), ("50", "50"), ("ddim50", "ddim50"),
+                                      ("10", "10"), ("sect", "10,15,20")])
+def test_diffusion_tables_exact(golden, tag, resp):
+    g = golden("schedules.npz")
+    d = su.create_gaussian_diffusion(steps=1000, learn_sigma=True, timestep_respacing=resp)
+    assert isinstance(d, SpacedDiffusion) and d.timestep_map == list(g[tag + "/timestep_map"])
+    assert d.num_timesteps == len(d.timestep_map) and d.original_num_steps == 1000
+    for n in TABLES:
+        assert np.array_equal(getattr(d, n), g[tag + "/" + n]), n
+    tab = d.coef_table()
+    assert tab.dtype == np.float32 and tab.shape == (d.num_timesteps, 8)
+    assert np.array_equal(tab[:, 0], g[tag + "/sqrt_recip_alphas_cumprod"].astype(np.float32))
+    assert np.array_equal(tab[:, 5], np.log(g[tag + "/betas"]).astype(np.float32))
+
+
+def test_space_timesteps_and_enums():
+    assert space_timesteps(1000, "ddim50") == set(range(0, 1000, 20))
+    assert sorted(space_timesteps(1000, "10"))[:3] == [0, 111, 222]
+    assert sorted(space_timesteps(300, [10, 15, 20]))[-1] == 299
+    with pytest.raises(ValueError):
+        space_timesteps(1000, "ddim999")
+    with pytest.raises(ValueError):
+        space_timesteps(10, "20")
+    d = su.create_gaussian_diffusion(learn_sigma=True)
+    assert d.model_mean_type == gd.ModelMeanType.EPSILON and d.model_var_type == gd.ModelVarType.LEARNED_RANGE
+    assert d.loss_type == gd.LossType.MSE and d.rescale_timesteps is False
+    d = su.create_gaussian_diffusion(learn_sigma=False, predict_xstart=True, use_kl=True)
+    assert d.model_var_type == gd.ModelVarType.FIXED_LARGE and d.model_mean_type == gd.ModelMeanType.START_X
+    assert d.loss_type == gd.LossType.RESCALED_KL and d.loss_type.is_vb()
+    # FIXED_LARGE log-variance row (gaussian_diffusion.py:281-284)
+    tab = d.coef_table()
+    want = np.log(np.append(d.posterior_variance[1], d.betas[1:])).astype(np.float32)
+    assert np.array_equal(tab[:, 4], want)
+
+
+def test_timestep_mapping_and_wrapped_model():
+    d = su.create_gaussian_diffusion(timestep_respacing="ddim50")
+    t = torch.tensor([0, 1, 49])
+    assert d._model_timesteps(t).tolist() == [0, 20, 980]
+    d2 = su.create_gaussian_diffusion(timestep_respacing="ddim50", rescale_timesteps=True, steps=500)
+    assert torch.allclose(d2._model_timesteps(t), torch.tensor([0.0, 20.0, 980.0]))  # 10-stride * 2.0
+    seen = {}
+    w = _WrappedModel(lambda x, ts, **kw: seen.update(ts=ts, kw=kw) or x, d.timestep_map, False, 1000)
+    w(torch.zeros(3), t, low_res=1)
+    assert seen["ts"].tolist() == [0, 20, 980] and seen["kw"] == {"low_res": 1}
+    assert d._wrap_model(w) is w
+
+
+def test_no_cpu_path():
+    """The product refuses CPU tensors / CPU models instead of silently computing elsewhere."""
+    fl = su.sr_model_and_diffusion_defaults()
+    fl.update(TINY, timestep_respacing="2")
+    model, diff = su.sr_create_model_and_diffusion(**fl)
+    x = torch.zeros(1, 1, 4, 8, 8)
+    with pytest.raises(RuntimeError, match="GPU"):
+        model(x, torch.tensor([0]), low_res=x)
+    with pytest.raises(RuntimeError, match="HIP"):
+        diff.p_sample_loop(model, (1, 1, 4, 8, 8), model_kwargs={"low_res": x})
+    src = open(os.path.join(ROOT, "3d-denoising-diffusion-model_amd", "guided_diffusion", "engine.py")).read()
+    assert "oracle" not in src
+
+
+def test_unsupported_features_fail_loudly():
+    from guided_diffusion.unet import UNetModel_noatt
+    with pytest.raises(NotImplementedError):
+        su.create_model(64, 32, 1)      # the 2-D RGB model of create_model_and_diffusion
+    with pytest.raises(NotImplementedError):
+        UNetModel_noatt(32, 2, 32, 2, 1, (), dims=3, num_classes=10)
+    d = su.create_gaussian_diffusion()
+    with pytest.raises(NotImplementedError):
+        next(d.p_sample_loop_progressive(None, (1, 1, 2, 2, 2), cond_fn=lambda *a: 0))
