@@ -136,9 +136,9 @@ int ddpm3d_gn_stats(const float* x, int N, int voxels, int C, float* stats, void
     return launched(ddpm3d_launch_gn_stats(x, N, voxels, C, stats, (hipStream_t)stream), "gn_stats");
 }
 
-int ddpm3d_timestep_embedding(const float* t, int rows, int dim, float max_period, float* out, void* stream) {
-    if (!t || !out || rows <= 0 || dim <= 1) return fail(DDPM3D_EINVAL, "timestep_embedding: bad arguments");
-    return launched(ddpm3d_launch_timestep_embedding(t, rows, dim, max_period, out, (hipStream_t)stream),
+int ddpm3d_timestep_embedding(const float* t, int rows, int dim, const float* freqs, float* out, void* stream) {
+    if (!t || !out || !freqs || rows <= 0 || dim <= 1) return fail(DDPM3D_EINVAL, "timestep_embedding: bad arguments");
+    return launched(ddpm3d_launch_timestep_embedding(t, rows, dim, freqs, out, (hipStream_t)stream),
                     "timestep_embedding");
 }
 

@@ -10,7 +10,7 @@ hipError_t ddpm3d_launch_gn_finalize(const float* st0, int C0, int rows0, const 
                                      int film_stride, int film_off, float* A, float* B, hipStream_t st);
 hipError_t ddpm3d_launch_gn_stats(const float* x, int N, int voxels, int C, float* stats, hipStream_t st);
 int ddpm3d_gn_stats_rows_impl(int voxels);
-hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, float max_period,
+hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, const float* freqs,
                                             float* out, hipStream_t st);
 hipError_t ddpm3d_launch_linear(const float* in, int rows, int K, const float* w, const float* bias, int O,
                                 int silu_in, float* out, int out_stride, hipStream_t st);

@@ -167,8 +167,8 @@ hipError_t ddpm3d_launch_gn_stats(const float* x, int N, int voxels, int C, floa
 int ddpm3d_gn_stats_rows_impl(int voxels) { return (voxels + GN_STATS_VOX - 1) / GN_STATS_VOX; }
 
 // ------------------------------------------------------ timestep embedding
-__global__ void timestep_embedding_kernel(const float* __restrict__ t, int rows, int dim, float max_period,
-                                          float* __restrict__ out) {
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int rows, int dim,
+                                          const float* __restrict__ freqs, float* __restrict__ out) {
     const int half = dim / 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * dim) return;
@@ -176,19 +176,19 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, int rows,
     float v = 0.0f;
     if (j < 2 * half) {
         const int f = j < half ? j : j - half;
-        // freqs = exp(-ln(max_period) * f / half), fp32 like nn.py:113-115
-        const float freq = expf(-logf(max_period) * (float)f / (float)half);
-        const float arg = t[r] * freq;
-        v = j < half ? cosf(arg) : sinf(arg);
+        // args = t * freqs in fp32 (nn.py:116); cos / sin evaluated in fp64 and rounded
+        // once, i.e. the correctly rounded fp32 value a <=1-ulp fp32 libm returns almost always
+        const float arg = t[r] * freqs[f];
+        v = j < half ? (float)cos((double)arg) : (float)sin((double)arg);
     }
     out[i] = v;
 }
 
-hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, float max_period,
+hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, const float* freqs,
                                             float* out, hipStream_t st) {
     const int total = rows * dim;
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, st, t, rows, dim,
-                       max_period, out);
+                       freqs, out);
     return hipGetLastError();
 }
 

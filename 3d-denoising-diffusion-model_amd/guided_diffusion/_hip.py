@@ -50,7 +50,7 @@ EXPORTS = {
                                      C.c_double, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ddpm3d_gn_stats_rows": (C.c_int, [C.c_int]),
     "ddpm3d_gn_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
-    "ddpm3d_timestep_embedding": (C.c_int, [_fp, C.c_int, C.c_int, C.c_float, _fp, _fp]),
+    "ddpm3d_timestep_embedding": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ddpm3d_linear": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp, C.c_int, _fp]),
     "ddpm3d_ncdhw_to_ndhwc": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_ndhwc_to_ncdhw": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),

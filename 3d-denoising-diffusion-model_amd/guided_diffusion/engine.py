@@ -19,6 +19,7 @@ for every step of the schedule.
 """
 
 import ctypes as C
+import math
 
 import torch
 
@@ -89,6 +90,11 @@ class UNetEngine:
             off += w.shape[0]
         self.film_total = off
         self.ted = 4 * model_channels
+        # frequency table of timestep_embedding, evaluated on the host exactly as the
+        # reference does (nn.py:113-115: th.exp(...) on CPU, then .to(device))
+        half = model_channels // 2
+        self.freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32)
+                               / half).to(device)
         self.emb_w = torch.cat(ws, 0).contiguous()
         self.emb_b = torch.cat(bs, 0).contiguous()
         torch.cuda.current_stream().synchronize()
@@ -103,7 +109,7 @@ class UNetEngine:
         e1 = torch.empty(R, self.ted, dtype=torch.float32, device=dev)
         e2 = torch.empty(R, self.ted, dtype=torch.float32, device=dev)
         rows = torch.empty(R, self.film_total, dtype=torch.float32, device=dev)
-        H.check(lib.ddpm3d_timestep_embedding(H.ptr(t_float), R, self.mc, 10000.0, H.ptr(temb), st))
+        H.check(lib.ddpm3d_timestep_embedding(H.ptr(t_float), R, self.mc, H.ptr(self.freqs), H.ptr(temb), st))
         H.check(lib.ddpm3d_linear(H.ptr(temb), R, self.mc, H.ptr(p["time_embed.0.weight"]),
                                   H.ptr(p["time_embed.0.bias"]), self.ted, 0, H.ptr(e1), self.ted, st))
         H.check(lib.ddpm3d_linear(H.ptr(e1), R, self.ted, H.ptr(p["time_embed.2.weight"]),
@@ -138,6 +144,8 @@ class _Plan:
         self.keep = []        # keeps ctypes structs / tensors alive
         self.film_patches = []  # gn_finalize arg lists whose film pointer is per call
         self.bias_patches = []  # (conv desc, film offset): additive-embedding conv1 bias rows
+        self.conv_meta = {}     # step index -> (kernel tag, algorithmic FLOPs)
+        self.timing = None      # set to a list to collect (tag, flops, start_evt, end_evt) per conv
         dev = eng.device
         topo = eng.topo
         lib = eng.lib
@@ -146,7 +154,9 @@ class _Plan:
             buf = torch.empty(N * d * h * w * Cn, dtype=torch.float32, device=dev)
             rows = lib.ddpm3d_conv_stats_rows(d, h, w, Cn, ks)
             stt = torch.empty(N * rows * Cn * 2, dtype=torch.float32, device=dev) if stats else None
-            return Act(buf, Cn, d, h, w, stt, rows)
+            act = Act(buf, Cn, d, h, w, stt, rows)
+            self.keep.append(act)  # descriptors hold raw pointers: the plan owns every buffer
+            return act
 
         self.new_act = new_act
         first = topo.input[0][0]
@@ -236,6 +246,12 @@ class _Plan:
         d.res_mode = res_mode
         d.res = H.ptr(res.buf) if res is not None else 0
         self.keep.append(d)
+        # bookkeeping for measurement: algorithmic FLOPs (2 per MAC) and the kernel
+        # instantiation the C side picks for this shape (conv3d_params.h rule)
+        wn = 4 if pc.Cout > 64 else (2 if pc.Cout > 32 else 1)
+        tile = 8 if (d.H >= 8 and d.W >= 8) else 4
+        flops = 2.0 * N * d.D * d.H * d.W * pc.Cout * d.Cin * pc.k ** 3
+        self.conv_meta[len(self.steps)] = ("conv3d_k%d_wn%d_t%d" % (pc.k, wn, tile), flops)
         self.steps.append((self.eng.lib.ddpm3d_conv3d, [C.byref(d), 0]))
         return d
 
@@ -310,11 +326,27 @@ class _Plan:
             dsc.bias_stride_n = film_stride
         target = out if out is not None else self.out_buf
         self.last_desc.out = target.data_ptr()
-        for fn, args in self.steps:
-            args[-1] = st
-            rc = fn(*args)
-            if rc != 0:
-                H.check(rc)
+        if self.timing is None:
+            for fn, args in self.steps:
+                args[-1] = st
+                rc = fn(*args)
+                if rc != 0:
+                    H.check(rc)
+        else:
+            # measurement replay: HIP events (on the stream the kernels are enqueued on)
+            # around every conv launch
+            for i, (fn, args) in enumerate(self.steps):
+                args[-1] = st
+                meta = self.conv_meta.get(i)
+                if meta is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                rc = fn(*args)
+                if rc != 0:
+                    H.check(rc)
+                if meta is not None:
+                    e1.record()
+                    self.timing.append((meta[0], meta[1], e0, e1))
         if out is not None:
             return out
         return self.out_buf

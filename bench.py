@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: denoised 64^3 PET sub-volumes per second at 250 DDPM
+steps (BASELINE.json), published architecture, fp32, synthetic data.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over one batch: p_sample_loop of
+`--ddpm-steps` (250) reverse steps on `--batch` (1) volume(s) of 1x64^3 per
+GPU, i.e. 250 UNet forwards + 250 fused sampler updates, device RNG included,
+inputs resident in HBM.  Ranks work on independent volumes (weak scaling, no
+collective inside a sample; one all_gather of the finished sample per step, as
+scripts/test.py:74-78 does).  Rank 0 prints ONE JSON line.
+
+roofline     : the conv3d implicit-GEMM kernel family (100 % of the path's
+               FLOPs).  HIP events around every conv launch of one UNet
+               forward per timed step; achieved = algorithmic FLOPs / event time.
+cpu_baseline : oracle/ (the CPU restatement pinned to the reference) timed on
+               this box's host cores on a bounded sample (a few p_sample steps
+               of the same workload), extrapolated to volumes/s.  N=1, rank 0.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "3d-denoising-diffusion-model_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PUBLISHED = dict(large_size=96, small_size=96, num_channels=128, num_res_blocks=2, num_head_channels=64,
+                 attention_resolutions="1000", learn_sigma=True, resblock_updown=True,
+                 use_scale_shift_norm=True)
+TINY = dict(PUBLISHED, num_channels=32, num_res_blocks=1)
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_model(arch, respacing, device):
+    from guided_diffusion import script_util as su
+    from guided_diffusion import synth
+    fl = su.sr_model_and_diffusion_defaults()
+    fl.update(arch, timestep_respacing=respacing)
+    model, diff = su.sr_create_model_and_diffusion(**fl)
+    t0 = time.time()
+    sd = {k: torch.from_numpy(synth.synth_param(k, tuple(v.shape))) for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    model.to(device).eval()
+    log("[bench] %d parameters synthesised in %.1fs" % (sum(v.numel() for v in sd.values()), time.time() - t0))
+    return model, diff, sd
+
+
+def cpu_baseline(arch, sd, size, respacing, n_steps, threads):
+    """Time the oracle's p_sample steps on the host cores (bounded sample)."""
+    from guided_diffusion import synth
+    from oracle import sampler_ref, schedule_ref, unet_ref
+    torch.set_num_threads(threads)
+    cfg = unet_ref.sr_config(**arch)
+    tmap, tb = schedule_ref.spaced_schedule(1000, "linear", respacing)
+    T = len(tmap)
+    shape = (1, 1, size, size, size)
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234))
+    draws = [torch.from_numpy(a) for a in synth.synth_noise(shape, n_steps + 2, seed=10)]
+    img = draws[0]
+    times = []
+    with torch.no_grad():
+        for k in range(n_steps + 1):   # first one is warm-up
+            i = T - 1 - k
+            t0 = time.time()
+            out = unet_ref.unet_forward(sd, cfg, img, torch.full((1,), tmap[i], dtype=torch.long), lr)
+            mean, log_var, _ = sampler_ref.mean_variance(tb, out, img, i, True, False, True)
+            img = mean + torch.exp(0.5 * log_var) * draws[k + 1]
+            times.append(time.time() - t0)
+            log("[bench] cpu oracle step %d: %.2fs" % (k, times[-1]))
+    per_step = float(np.mean(times[1:]))
+    return {
+        "value": 1.0 / (per_step * T),
+        "unit": "volumes/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d p_sample steps (after 1 warm-up) of the same 1x%d^3 published-arch workload, "
+                  "%.2f s/step, extrapolated x%d steps" % (n_steps, size, per_step, T),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ddpm-steps", type=int, default=250)
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
+    ap.add_argument("--arch", choices=["published", "tiny"], default="published")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.gpus != world:
+        log("[bench] note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from guided_diffusion import synth
+    arch = PUBLISHED if args.arch == "published" else TINY
+    respacing = str(args.ddpm_steps)
+    model, diff, sd = build_model(arch, respacing, device)
+    B, S = args.batch, args.size
+    shape = (B, 1, S, S, S)
+    lr = torch.from_numpy(np.stack([synth.synth_low_res((1, S, S, S), seed=1234 + rank * 1000 + b)
+                                    for b in range(B)])).to(device)
+    eng = model.engine()
+    plan = eng.plan(B, S, S, S)
+    flops_fwd = sum(f for _, f in plan.conv_meta.values())
+    T = diff.num_timesteps
+
+    def one_volume(step_index, measure):
+        # per-volume noise keyed by the GLOBAL volume index, so results do not depend on world size
+        gen = torch.Generator(device=device)
+        gen.manual_seed(10 + step_index * world + rank)
+        noise = torch.randn(*shape, device=device, generator=gen)
+        torch.manual_seed(1000 + step_index * world + rank)
+        timing = []
+        k = 0
+        final = None
+        for final in diff.p_sample_loop_progressive(model, shape, noise, model_kwargs={"low_res": lr}):
+            k += 1
+            plan.timing = timing if (measure and k == T // 2) else None   # instrument ONE forward
+        plan.timing = None
+        sample = final["sample"]
+        if world > 1:
+            gathered = [torch.empty_like(sample) for _ in range(world)]
+            dist.all_gather(gathered, sample)
+        return sample, timing
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        t0 = time.time()
+        one_volume(-1 - w, False)
+        torch.cuda.synchronize()
+        log("[bench] rank %d warm-up volume %d: %.2fs" % (rank, w, time.time() - t0))
+
+    timings = []
+    sync()
+    t_start = time.time()
+    for s in range(args.steps):
+        sample, tm = one_volume(s, True)
+        timings += tm
+        if rank == 0:
+            torch.cuda.synchronize()
+            log("[bench] step %d done at %.2fs" % (s, time.time() - t_start))
+    sync()
+    elapsed = time.time() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(sample).all()
+
+    # roofline of the conv kernel family, from the instrumented forwards
+    by_tag = {}
+    for tag, fl, e0, e1 in timings:
+        ms = e0.elapsed_time(e1)
+        a = by_tag.setdefault(tag, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += fl
+        a[2] += ms
+    tot_fl = sum(a[1] for a in by_tag.values())
+    tot_ms = sum(a[2] for a in by_tag.values())
+    dom = max(by_tag.items(), key=lambda kv: kv[1][2]) if by_tag else None
+    roof = None
+    if dom:
+        tag, (cnt, fl, ms) = dom
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {
+            "bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches_timed": cnt, "avg_launch_ms": round(ms / cnt, 4),
+            "all_conv_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                 "ms_per_forward": round(tot_ms / max(1, args.steps), 3),
+                                 "gflop_per_forward": round(flops_fwd / 1e9, 1)},
+            "per_kernel": {t: {"launches": a[0], "tflops": round(a[1] / (a[2] * 1e-3) / 1e12, 2),
+                               "ms": round(a[2] / max(1, args.steps), 3)} for t, a in sorted(by_tag.items())},
+        }
+
+    if rank == 0:
+        vols = args.steps * B * world
+        res = {
+            "metric": "denoised 64^3 volumes/sec @250 DDPM steps",
+            "value": vols / elapsed,
+            "unit": "volumes/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "%dx1x%d^3 volume(s) per GPU, %d DDPM steps, %s architecture "
+                                   "(SuperResModel_noatt, %d base ch, mult (1,1,2,3,4), %d res blocks, "
+                                   "learn_sigma), seeded random weights, device RNG"
+                                   % (B, S, T, args.arch, arch["num_channels"], arch["num_res_blocks"]),
+                       "parallelism": "independent volumes per rank (dp%d), all_gather of finished samples" % world,
+                       "tflop_per_volume": round(flops_fwd * T / B / 1e12, 1)},
+            "roofline": roof,
+        }
+        if world == 1 and args.cpu_steps > 0:
+            threads = os.cpu_count() or 1
+            try:
+                threads = len(os.sched_getaffinity(0))
+            except Exception:
+                pass
+            sd_cpu = {k: v for k, v in sd.items()}
+            res["cpu_baseline"] = cpu_baseline(arch, sd_cpu, S, respacing, args.cpu_steps, threads)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

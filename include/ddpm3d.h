@@ -148,8 +148,11 @@ int ddpm3d_gn_finalize(const float* stats0, int C0, int rows0,
 int ddpm3d_gn_stats_rows(int voxels);
 int ddpm3d_gn_stats(const float* x, int N, int voxels, int C, float* stats, void* stream);
 
-/* nn.py:103-121 timestep_embedding: out[r] = [cos(t_r f) | sin(t_r f)] (+0 pad) */
-int ddpm3d_timestep_embedding(const float* t, int rows, int dim, float max_period,
+/* nn.py:103-121 timestep_embedding: out[r] = [cos(t_r f) | sin(t_r f)] (+0 pad).
+ * freqs = [dim/2] fp32 table.  The reference evaluates
+ * exp(-ln(max_period) * arange(half) / half) on the HOST and moves it to the
+ * device (nn.py:113-115), so the table is a host-computed constant here too. */
+int ddpm3d_timestep_embedding(const float* t, int rows, int dim, const float* freqs,
                               float* out, void* stream);
 /* nn.Linear (time_embed unet.py:799-803, emb_layers unet.py:199-205):
  * out[r][o] = bias[o] + sum_k f(in[r][k]) * w[o][k],  f = SiLU if silu_in */

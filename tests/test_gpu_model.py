@@ -74,7 +74,7 @@ def test_unet_forward_vs_oracle_layerwise():
     model, _ = build(TINY)
     cfg = unet_ref.sr_config(**TINY)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    x, lr = inputs((2, 1, 6, 24, 40))
+    x, lr = inputs((2, 1, 6, 32, 48))
     t = torch.tensor([0, 640])
     with torch.no_grad():
         ref = unet_ref.unet_forward(sd, cfg, x, t, lr)
