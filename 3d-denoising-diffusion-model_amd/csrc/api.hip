@@ -28,31 +28,31 @@ extern "C" {
 int ddpm3d_abi_version(void) { return DDPM3D_ABI_VERSION; }
 const char* ddpm3d_last_error(void) { return g_err; }
 
-size_t ddpm3d_packed_weight_elems(int Cout, int Cin, int ksize) {
-    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;
-    return (size_t)ksize * ksize * ksize * ddpm3d_cin_pad(Cin) * ddpm3d_cout_pad(Cout);
+static bool prec_ok(int p) { return p == DDPM3D_PREC_F32 || p == DDPM3D_PREC_F16X3; }
+
+size_t ddpm3d_packed_weight_bytes(int Cout, int Cin, int ksize, int precision) {
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || !prec_ok(precision)) return 0;
+    return ddpm3d_packed_bytes(Cout, Cin, ksize, precision);
 }
 
-int ddpm3d_pack_conv_weight(const float* w, int Cout, int Cin, int ksize, float* out, void* stream) {
-    if (!w || !out || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3))
-        return fail(DDPM3D_EINVAL, "pack_conv_weight: bad arguments (Cout=%d Cin=%d k=%d)", Cout, Cin, ksize);
+int ddpm3d_pack_conv_weight(const float* w, int Cout, int Cin, int ksize, int precision, void* out,
+                            void* stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || !prec_ok(precision))
+        return fail(DDPM3D_EINVAL, "pack_conv_weight: bad arguments (Cout=%d Cin=%d k=%d precision=%d)", Cout,
+                    Cin, ksize, precision);
     if (!aligned16(out)) return fail(DDPM3D_EINVAL, "pack_conv_weight: w_packed must be 16-byte aligned");
-    return launched(ddpm3d_launch_pack(w, Cout, Cin, ksize, out, (hipStream_t)stream), "pack_conv_weight");
+    return launched(ddpm3d_launch_pack(w, Cout, Cin, ksize, precision, out, (hipStream_t)stream),
+                    "pack_conv_weight");
 }
 
-static void conv_tiles(const ConvCfg& c, int D, int H, int W, int* tz, int* ty, int* tx) {
-    const int TX = 1 << c.TXL, TY = 1 << c.TYL, TZ = 128 / (TX * TY);
-    *tx = (W + TX - 1) / TX;
-    *ty = (H + TY - 1) / TY;
-    *tz = (D + TZ - 1) / TZ;
+int ddpm3d_conv_stats_rows(int N, int D, int H, int W, int Cin, int Cout, int ksize) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return ddpm3d_conv_cfg(N, D, H, W, Cin, Cout, ksize).stats_rows;
 }
 
-int ddpm3d_conv_stats_rows(int D, int H, int W, int Cout, int ksize) {
-    if (D <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
-    const ConvCfg c = ddpm3d_conv_cfg(H, W, Cout, ksize);
-    int tz, ty, tx;
-    conv_tiles(c, D, H, W, &tz, &ty, &tx);
-    return tz * ty * tx * (4 / c.WN);
+size_t ddpm3d_conv_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int ksize) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return ddpm3d_conv_cfg(N, D, H, W, Cin, Cout, ksize).workspace_bytes;
 }
 
 int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
@@ -61,7 +61,7 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         return fail(DDPM3D_EINVAL, "conv3d: non-positive shape N=%d D=%d H=%d W=%d Cin=%d Cout=%d", d->N, d->D,
                     d->H, d->W, d->Cin, d->Cout);
     if (d->ksize != 1 && d->ksize != 3) return fail(DDPM3D_EINVAL, "conv3d: ksize %d (1 or 3)", d->ksize);
-    if (d->precision != 0) return fail(DDPM3D_ENOSUP, "conv3d: precision mode %d not implemented", d->precision);
+    if (!prec_ok(d->precision)) return fail(DDPM3D_ENOSUP, "conv3d: precision mode %d not implemented", d->precision);
     if (d->C0 + d->C1 != d->Cin) return fail(DDPM3D_EINVAL, "conv3d: C0+C1 != Cin");
     if (!d->src0 || !d->w_packed || !d->bias || !d->out) return fail(DDPM3D_EINVAL, "conv3d: null buffer");
     if (d->in_mode == DDPM3D_IN_PLANAR2) {
@@ -89,25 +89,38 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     if (d->out_layout != DDPM3D_OUT_NDHWC && d->out_layout != DDPM3D_OUT_NCDHW)
         return fail(DDPM3D_EINVAL, "conv3d: out_layout %d", d->out_layout);
 
-    const ConvCfg c = ddpm3d_conv_cfg(d->H, d->W, d->Cout, d->ksize);
+    ConvCfg c = ddpm3d_conv_cfg(d->N, d->D, d->H, d->W, d->Cin, d->Cout, d->ksize);
+    c.PREC = d->precision;
+    if (c.S > 1 && (!d->workspace || d->workspace_bytes < c.workspace_bytes || !aligned16(d->workspace)))
+        return fail(DDPM3D_EINVAL, "conv3d: this shape is split %d-way over Cin and needs %zu bytes of "
+                                   "16-byte aligned workspace (got %zu)", c.S, c.workspace_bytes,
+                    d->workspace ? d->workspace_bytes : (size_t)0);
     ConvK k;
     memset(&k, 0, sizeof(k));
     k.src0 = d->src0; k.src1 = d->src1; k.affA = d->aff_a; k.affB = d->aff_b;
-    k.w = d->w_packed; k.bias = d->bias; k.res = d->res; k.out = d->out; k.stats = d->stats;
+    k.w = (const float*)d->w_packed; k.bias = d->bias; k.res = d->res; k.out = d->out; k.stats = d->stats;
     k.N = d->N; k.D = d->D; k.H = d->H; k.W = d->W; k.Cin = d->Cin; k.Cout = d->Cout;
     k.C0 = d->C0; k.C1 = d->C1;
     k.CinPad = ddpm3d_cin_pad(d->Cin); k.CoutPad = ddpm3d_cout_pad(d->Cout);
     k.in_mode = d->in_mode; k.act = d->act; k.bias_stride_n = d->bias_stride_n;
     k.res_mode = d->res_mode; k.out_layout = d->out_layout;
-    conv_tiles(c, d->D, d->H, d->W, &k.tilesZ, &k.tilesY, &k.tilesX);
-    k.stats_rows = k.tilesZ * k.tilesY * k.tilesX * (4 / c.WN);
+    k.tilesZ = c.tilesZ; k.tilesY = c.tilesY; k.tilesX = c.tilesX;
+    k.stats_rows = c.stats_rows;
+    k.ksplit = c.S;
+    k.chunks_per_split = (k.CinPad / DDPM3D_CONV_CK + c.S - 1) / c.S;
+    k.partial = (float*)d->workspace;
+    if (c.PREC == DDPM3D_PREC_F16X3)  // output scales sit behind the f16 image
+        k.wscale = (const float*)((const char*)d->w_packed +
+                                  ddpm3d_packed_bytes(d->Cout, d->Cin, d->ksize, 0));
     if (d->stats && d->stats_rows != k.stats_rows)
         return fail(DDPM3D_EINVAL, "conv3d: stats_rows=%d, this shape writes %d", d->stats_rows, k.stats_rows);
     if (d->stats && d->out_layout != DDPM3D_OUT_NDHWC)
         return fail(DDPM3D_EINVAL, "conv3d: statistics only with NDHWC output");
     const long long blocks = (long long)k.N * k.tilesZ * k.tilesY * k.tilesX;
     if (blocks > 0x7fffffffLL) return fail(DDPM3D_EINVAL, "conv3d: grid too large");
-    return launched(ddpm3d_launch_conv_f32(k, c, (hipStream_t)stream), "conv3d");
+    const int rc = launched(ddpm3d_launch_conv(k, c, (hipStream_t)stream), "conv3d");
+    if (rc != DDPM3D_OK || c.S == 1) return rc;
+    return launched(ddpm3d_launch_splitk_reduce(k, (hipStream_t)stream), "conv3d split-K reduce");
 }
 
 int ddpm3d_gn_finalize(const float* stats0, int C0, int rows0, const float* stats1, int C1, int rows1,

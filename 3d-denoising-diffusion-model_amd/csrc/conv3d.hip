@@ -1,41 +1,40 @@
-// Fused 3-D convolution for gfx950 (MI355X): implicit GEMM on the fp32 matrix
-// cores with the GroupNorm-apply / SiLU / FiLM / pool / upsample / concat
-// prologue and the bias / residual / GroupNorm-statistics epilogue fused in.
+// Fused 3-D convolution for gfx950 (MI355X): implicit GEMM on the matrix cores
+// with the GroupNorm-apply / SiLU / FiLM / pool / upsample / concat prologue
+// and the bias / residual / GroupNorm-statistics epilogue fused in.
 //
 //   GEMM view      M = output voxels, N = Cout, K = taps * Cin
 //   workgroup      256 threads = 4 waves, tile = 128 voxels x (32*WN) couts
 //   wave (wm, wn)  MT 32x32 accumulators: 32*MT voxels x 32 couts
-//   A operand      input halo tile [voxel][CK ci] staged ONCE per ci-chunk in
+//   A operand      input halo tile [voxel][16 ci] staged ONCE per ci-chunk in
 //                  LDS (already normalised+activated), read per tap at a
-//                  constant LDS offset (ds_read_b128, 4 k-steps per read)
-//   B operand      packed weights streamed L2 -> VGPR (global_load_dwordx4,
-//                  one per 4 k-steps), private to the wave's 32 couts
-//   MFMA           v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain)
+//                  constant LDS offset (ds_read_b128)
+//   B operand      packed weights streamed L2 -> VGPR (global_load_dwordx4),
+//                  private to the wave's 32 couts, prefetched one tap ahead
+//   split-K        blockIdx.z owns a range of the ci-chunks (low-res levels)
 //
-// K order inside an 8-channel block is permuted (lane half h supplies channel
-// 4h+s at step s) so that both operands are 16-byte loads; the weight packer
-// (pack.hip) stores that order.
+// Two arithmetic modes (template PREC), same fp32 inputs, outputs and
+// accumulators:
+//   PREC 0  v_mfma_f32_32x32x2_f32: exact fp32 products (bitwise an fmaf chain),
+//           64 FLOP/clk/SIMD.
+//   PREC 1  each fp32 operand is split x = hi + lo into two f16 (after a
+//           power-of-two scaling that keeps lo out of the f16 subnormals) and
+//           a*b is evaluated as hi*hi + hi*lo + lo*hi on
+//           v_mfma_f32_32x32x16_f16 (every f16 x f16 product is exact in fp32).
+//           Operand representation error ~2^-23 relative -- below the fp32
+//           accumulation error both modes share -- at 16/3 the MFMA rate.
+//
+// K order inside a channel block is permuted in PREC 0 (lane half h supplies
+// channel 4h+s at step s) so both operands are 16-byte loads; the weight packer
+// (ops.hip) stores the order each mode reads.
 #include <hip/hip_runtime.h>
-#include "conv3d_params.h"
+#include "conv3d_load.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
-
-template <int ACT>
-__device__ __forceinline__ f32x4 affine_act(f32x4 v, f32x4 a, f32x4 b) {
-    f32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float y = fmaf(v[i], a[i], b[i]);
-        r[i] = ACT ? silu_f(y) : y;
-    }
-    return r;
-}
-
-template <int KS, int CK, int WN, int TXL, int TYL>
-__global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const ConvK p) {
+template <int PREC, int KS, int WN, int TXL, int TYL>
+__global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
+    constexpr int CK = DDPM3D_CONV_CK;
     constexpr int WM = 4 / WN;
     constexpr int MT = 4 / WM;  // 32-row accumulators per wave; tile is always 128 voxels
     constexpr int TX = 1 << TXL, TY = 1 << TYL;
@@ -43,12 +42,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const ConvK p) {
     constexpr int PAD = KS / 2;
     constexpr int HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = TZ + 2 * PAD;
     constexpr int HV = HX * HY * HZ;
-    constexpr int RS = CK + 4;  // LDS row stride (floats): conflict-light b128 reads
+    // LDS row = one halo voxel = 80 bytes in both modes:
+    //   PREC 0: 16 floats + 4 pad;  PREC 1: 16 f16 hi | 16 f16 lo | 8 f16 pad
+    // (5 x 16-byte slots per row: consecutive rows rotate over the 16 slots of the
+    //  ds_read_b128 bank row, so the fragment reads are conflict-light)
+    constexpr int RSB = 80;
     constexpr int QPV = CK / 4;
-    constexpr int KK = CK / 8;
     constexpr int NT = KS * KS * KS;
 
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -56,36 +58,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const ConvK p) {
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5;
 
-    // XCD-aware tile order: consecutive tiles (which share halo planes) on one XCD's L2
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    int tile = bid;
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tx_i = tile % p.tilesX; tile /= p.tilesX;
     const int ty_i = tile % p.tilesY; tile /= p.tilesY;
     const int tz_i = tile % p.tilesZ; tile /= p.tilesZ;
     const int n = tile;
     const int x0 = tx_i * TX, y0 = ty_i * TY, z0 = tz_i * TZ;
 
-    // per-lane A row offsets (floats) at tap (0,0,0), k-offset of this half
+    // per-lane A row byte offsets at tap (0,0,0), including this half's 16-byte k-slot
     int arow[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = (wm * MT + t) * 32 + (lane & 31);
         const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
-        arow[t] = ((tz * HY + ty) * HX + tx) * RS + half * 4;
+        arow[t] = ((tz * HY + ty) * HX + tx) * RSB + half * 16;
     }
 
     const int cout = blockIdx.y * (32 * WN) + wn * 32 + (lane & 31);
     const bool wave_active = (blockIdx.y * (32 * WN) + wn * 32) < p.CoutPad;
     const int cout_ld = wave_active ? cout : 0;
-    // float4 index of this lane's first weight quad
-    const f32x4* wbase = reinterpret_cast<const f32x4*>(p.w) + ((size_t)cout_ld * 2 + half);
-    const size_t wtap_stride = (size_t)(p.CinPad / 8) * p.CoutPad * 2;  // float4 per tap
-    const size_t wcb_stride = (size_t)p.CoutPad * 2;                     // float4 per 8-ci block
+    // Weight stream in 16-byte units.
+    //   PREC 0: [tap][ci/8][CoutPad][8 f32]            -> 2 units per (8-ci block, cout)
+    //   PREC 1: [tap][ci/16][hi|lo][CoutPad][16 f16]   -> 2 units per (16-ci block, part, cout)
+    const uint4* wbase = reinterpret_cast<const uint4*>(p.w) + ((size_t)cout_ld * 2 + half);
+    const size_t wpart = (size_t)p.CoutPad * 2;                       // PREC0: next 8-ci block; PREC1: hi -> lo
+    const size_t wchunk_stride = 2 * wpart;                           // one 16-ci chunk
+    const size_t wtap_stride = (size_t)(p.CinPad / CK) * wchunk_stride;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -93,107 +91,85 @@ __global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const ConvK p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 
-    // source geometry
-    const int Hs = p.in_mode == DDPM3D_IN_POOL ? 2 * p.H : (p.in_mode == DDPM3D_IN_UP ? p.H / 2 : p.H);
-    const int Ws = p.in_mode == DDPM3D_IN_POOL ? 2 * p.W : (p.in_mode == DDPM3D_IN_UP ? p.W / 2 : p.W);
-
     const int nchunks = p.CinPad / CK;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int c0 = chunk * CK;
+    // split-K: blockIdx.z owns a contiguous range of the Cin chunks
+    const int chunk_begin = blockIdx.z * p.chunks_per_split;
+    const int chunk_end = min(nchunks, chunk_begin + p.chunks_per_split);
+    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         __syncthreads();  // everyone done reading the previous chunk's tile
         // ------------------------------------------------ stage the halo tile
         {
-            const bool from0 = c0 < p.C0;
-            const float* __restrict__ src = from0 ? p.src0 : p.src1;
-            const int Cs = from0 ? p.C0 : p.C1;
-            const int cb = from0 ? c0 : c0 - p.C0;
             const int q = tid % QPV;  // fixed per thread: 256 % QPV == 0
-            f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
-            const bool has_aff = p.affA != nullptr;
-            if (has_aff && p.in_mode != DDPM3D_IN_PLANAR2) {
-                ga = *reinterpret_cast<const f32x4*>(p.affA + (size_t)n * p.Cin + c0 + q * 4);
-                gb = *reinterpret_cast<const f32x4*>(p.affB + (size_t)n * p.Cin + c0 + q * 4);
-            }
+            const HaloSrc hs = halo_src<CK>(p, n, chunk, q);
             for (int idx = tid; idx < HV * QPV; idx += 256) {
                 const int hv = idx / QPV;
                 const int hz = hv / (HY * HX);
                 const int rem = hv - hz * (HY * HX);
                 const int hy = rem / HX;
                 const int hx = rem - hy * HX;
-                const int z = z0 - PAD + hz, y = y0 - PAD + hy, x = x0 - PAD + hx;
-                const bool inb = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H &&
-                                 (unsigned)x < (unsigned)p.W;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (inb) {
-                    if (p.in_mode == DDPM3D_IN_SAME) {
-                        const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
-                        v = *reinterpret_cast<const f32x4*>(src + vox * Cs + cb + q * 4);
-                        if (has_aff) v = p.act ? affine_act<1>(v, ga, gb) : affine_act<0>(v, ga, gb);
-                    } else if (p.in_mode == DDPM3D_IN_UP) {
-                        const size_t vox = (((size_t)n * p.D + z) * Hs + (y >> 1)) * Ws + (x >> 1);
-                        v = *reinterpret_cast<const f32x4*>(src + vox * Cs + cb + q * 4);
-                        if (has_aff) v = p.act ? affine_act<1>(v, ga, gb) : affine_act<0>(v, ga, gb);
-                    } else if (p.in_mode == DDPM3D_IN_POOL) {
-                        // AvgPool3d window order (h, w): ((s00 + s01) + s10) + s11, then / 4
-                        const size_t vox = (((size_t)n * p.D + z) * Hs + 2 * y) * Ws + 2 * x;
-                        const float* b0 = src + vox * Cs + cb + q * 4;
-                        f32x4 s00 = *reinterpret_cast<const f32x4*>(b0);
-                        f32x4 s01 = *reinterpret_cast<const f32x4*>(b0 + Cs);
-                        f32x4 s10 = *reinterpret_cast<const f32x4*>(b0 + (size_t)Ws * Cs);
-                        f32x4 s11 = *reinterpret_cast<const f32x4*>(b0 + (size_t)Ws * Cs + Cs);
-                        if (has_aff) {
-                            if (p.act) {
-                                s00 = affine_act<1>(s00, ga, gb); s01 = affine_act<1>(s01, ga, gb);
-                                s10 = affine_act<1>(s10, ga, gb); s11 = affine_act<1>(s11, ga, gb);
-                            } else {
-                                s00 = affine_act<0>(s00, ga, gb); s01 = affine_act<0>(s01, ga, gb);
-                                s10 = affine_act<0>(s10, ga, gb); s11 = affine_act<0>(s11, ga, gb);
-                            }
-                        }
-                        v = (((s00 + s01) + s10) + s11) * 0.25f;
-                    } else {  // PLANAR2: two single-channel volumes, channels 0 and 1 of the chunk
-                        if (q == 0 && chunk == 0) {
-                            const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
-                            v[0] = p.src0[vox];
-                            v[1] = p.src1[vox];
-                        }
+                const f32x4 v = halo_fetch<PREC == 1>(p, hs, n, z0 - PAD + hz, y0 - PAD + hy, x0 - PAD + hx, q,
+                                                      chunk == 0);
+                if constexpr (PREC == 0) {
+                    *reinterpret_cast<f32x4*>(lds + hv * RSB + q * 16) = v;
+                } else {
+                    h4 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        // x8: keeps lo = x - hi a normal f16 down to |x| ~ 2^-6; clamp keeps hi finite
+                        const float s = fminf(fmaxf(v[i] * DDPM3D_X3_ACT_SCALE, -60000.0f), 60000.0f);
+                        hi[i] = (_Float16)s;
+                        lo[i] = (_Float16)(s - (float)hi[i]);
                     }
+                    *reinterpret_cast<h4*>(lds + hv * RSB + q * 8) = hi;
+                    *reinterpret_cast<h4*>(lds + hv * RSB + 32 + q * 8) = lo;
                 }
-                *reinterpret_cast<f32x4*>(lds + hv * RS + q * 4) = v;
             }
         }
         __syncthreads();
         if (!wave_active) continue;
 
         // ------------------------------------------------ taps x k-steps
-        const f32x4* wchunk = wbase + (size_t)chunk * KK * wcb_stride;
-        f32x4 bcur[KK], bnxt[KK];
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) bcur[kk] = wchunk[kk * wcb_stride];
+        const uint4* wchunk = wbase + (size_t)chunk * wchunk_stride;
+        uint4 bcur[2], bnxt[2];
+        bcur[0] = wchunk[0];
+        bcur[1] = wchunk[wpart];
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
             if (tap + 1 < NT) {
-#pragma unroll
-                for (int kk = 0; kk < KK; ++kk)
-                    bnxt[kk] = wchunk[(size_t)(tap + 1) * wtap_stride + kk * wcb_stride];
+                bnxt[0] = wchunk[(size_t)(tap + 1) * wtap_stride];
+                bnxt[1] = wchunk[(size_t)(tap + 1) * wtap_stride + wpart];
             }
             const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-            const int tapoff = ((dz * HY + dy) * HX + dx) * RS;
+            const int tapoff = ((dz * HY + dy) * HX + dx) * RSB;
+            if constexpr (PREC == 0) {
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-                f32x4 a[MT];
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    a[t] = *reinterpret_cast<const f32x4*>(lds + arow[t] + tapoff + kk * 8);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
+                for (int kk = 0; kk < 2; ++kk) {
+                    f32x4 a[MT];
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], bcur[kk][s], acc[t], 0, 0, 0);
+                        a[t] = *reinterpret_cast<const f32x4*>(lds + arow[t] + tapoff + kk * 32);
+                    const f32x4 b = __builtin_bit_cast(f32x4, bcur[kk]);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], b[s], acc[t], 0, 0, 0);
+                }
+            } else {
+                const h8 bhi = __builtin_bit_cast(h8, bcur[0]);
+                const h8 blo = __builtin_bit_cast(h8, bcur[1]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const h8 ahi = *reinterpret_cast<const h8*>(lds + arow[t] + tapoff);
+                    const h8 alo = *reinterpret_cast<const h8*>(lds + arow[t] + tapoff + 32);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[t], 0, 0, 0);
+                }
             }
             if (tap + 1 < NT) {
-#pragma unroll
-                for (int kk = 0; kk < KK; ++kk) bcur[kk] = bnxt[kk];
+                bcur[0] = bnxt[0];
+                bcur[1] = bnxt[1];
             }
         }
     }
@@ -203,9 +179,30 @@ __global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const ConvK p) {
     // ---------------------------------------------------------- epilogue
     // C/D map of 32x32 MFMA: col = lane&31 (cout), row = (reg&3) + 8*(reg>>2) + 4*half
     const bool cvalid = cout < p.Cout;
+    const size_t DHW = (size_t)p.D * p.H * p.W;
+    // PREC 1: undo the operand scaling (exact: a power of two per cout)
+    const float oscale = (PREC == 1 && cvalid) ? p.wscale[cout] : 1.0f;
+    if (p.ksplit > 1) {
+        // split-K: raw partial sums to this split's slab; bias / residual / statistics
+        // are applied by the reduce kernel once all splits are in
+        float* slab = p.partial + ((size_t)blockIdx.z * p.N + n) * DHW * p.Cout;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                const int m = (wm * MT + t) * 32 + row;
+                const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
+                const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
+                if (cvalid && z < p.D && y < p.H && x < p.W)
+                    slab[(((size_t)z * p.H + y) * p.W + x) * p.Cout + cout] =
+                        PREC == 1 ? acc[t][reg] * oscale : acc[t][reg];
+            }
+        }
+        return;
+    }
     const float bias = cvalid ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
     float s1 = 0.0f, s2 = 0.0f;
-    const size_t DHW = (size_t)p.D * p.H * p.W;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -216,22 +213,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const ConvK p) {
             const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
             const bool ok = cvalid && z < p.D && y < p.H && x < p.W;
             if (ok) {
-                float val = acc[t][reg] + bias;
+                float val = (PREC == 1 ? acc[t][reg] * oscale : acc[t][reg]) + bias;
                 const size_t vox = ((size_t)z * p.H + y) * p.W + x;
-                if (p.res_mode == DDPM3D_RES_SAME) {
-                    val += p.res[((size_t)n * DHW + vox) * p.Cout + cout];
-                } else if (p.res_mode == DDPM3D_RES_UP) {
-                    const int Hr = p.H / 2, Wr = p.W / 2;
-                    const size_t rv = (((size_t)n * p.D + z) * Hr + (y >> 1)) * Wr + (x >> 1);
-                    val += p.res[rv * p.Cout + cout];
-                } else if (p.res_mode == DDPM3D_RES_POOL) {
-                    const int Hr = p.H * 2, Wr = p.W * 2;
-                    const size_t rv = (((size_t)n * p.D + z) * Hr + 2 * y) * Wr + 2 * x;
-                    const float* r0 = p.res + rv * p.Cout + cout;
-                    const float r = ((r0[0] + r0[p.Cout]) + r0[(size_t)Wr * p.Cout]) +
-                                    r0[(size_t)Wr * p.Cout + p.Cout];
-                    val += r * 0.25f;
-                }
+                if (p.res_mode != DDPM3D_RES_NONE) val += ddpm3d_residual(p, n, z, y, x, cout);
                 if (p.out_layout == DDPM3D_OUT_NDHWC)
                     p.out[((size_t)n * DHW + vox) * p.Cout + cout] = val;
                 else
@@ -253,30 +237,75 @@ __global__ __launch_bounds__(256, 2) void conv3d_f32_kernel(const ConvK p) {
     }
 }
 
+// ------------------------------------------------------- split-K reduction
+// out = sum_s slab[s] + bias + residual, plus the GroupNorm partial sums the
+// conv epilogue would have written.  One workgroup per DDPM3D_REDUCE_VOX
+// voxels of one sample (= one statistics row); threads run along Cout, so every
+// slab / residual / output access is a contiguous row segment.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) {
+    const size_t DHW = (size_t)p.D * p.H * p.W;
+    const int rows = p.stats_rows;
+    const int n = blockIdx.x / rows, r = blockIdx.x % rows;
+    const size_t v0 = (size_t)r * DDPM3D_REDUCE_VOX;
+    const size_t v1 = min(v0 + (size_t)DDPM3D_REDUCE_VOX, DHW);
+    const size_t slab_stride = (size_t)p.N * DHW * p.Cout;
+    for (int cout = threadIdx.x; cout < p.Cout; cout += 256) {
+        const float bias = p.bias[(size_t)n * p.bias_stride_n + cout];
+        float s1 = 0.0f, s2 = 0.0f;
+        for (size_t v = v0; v < v1; ++v) {
+            const size_t e = ((size_t)n * DHW + v) * p.Cout + cout;
+            float val = p.partial[e];
+            for (int s = 1; s < p.ksplit; ++s) val += p.partial[e + s * slab_stride];
+            val += bias;
+            if (p.res_mode != DDPM3D_RES_NONE) {
+                const int x = (int)(v % p.W), y = (int)((v / p.W) % p.H), z = (int)(v / ((size_t)p.W * p.H));
+                val += ddpm3d_residual(p, n, z, y, x, cout);
+            }
+            if (p.out_layout == DDPM3D_OUT_NDHWC)
+                p.out[e] = val;
+            else
+                p.out[((size_t)n * p.Cout + cout) * DHW + v] = val;
+            s1 += val;
+            s2 = fmaf(val, val, s2);
+        }
+        if (p.stats != nullptr) {
+            float2 v2 = make_float2(s1, s2);
+            *reinterpret_cast<float2*>(p.stats + (((size_t)n * rows + r) * p.Cout + cout) * 2) = v2;
+        }
+    }
+}
+
+hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st) {
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(k.N * k.stats_rows), dim3(256), 0, st, k);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- dispatch
-template <int KS, int WN, int TXL, int TYL>
+template <int PREC, int KS, int WN, int TXL, int TYL>
 static hipError_t launch_cfg(const ConvK& k, int grid_x, int grid_y, hipStream_t st) {
-    constexpr int CK = DDPM3D_CONV_CK;
-    constexpr int WM = 4 / WN;
     constexpr int TX = 1 << TXL, TY = 1 << TYL, TZ = 128 / (TX * TY);
     constexpr int PAD = KS / 2;
     constexpr int HV = (TX + 2 * PAD) * (TY + 2 * PAD) * (TZ + 2 * PAD);
-    constexpr size_t lds_bytes = (size_t)HV * (CK + 4) * sizeof(float);
-    (void)WM;
-    hipLaunchKernelGGL((conv3d_f32_kernel<KS, CK, WN, TXL, TYL>), dim3(grid_x, grid_y, 1), dim3(256),
+    constexpr size_t lds_bytes = (size_t)HV * 80;
+    hipLaunchKernelGGL((conv3d_kernel<PREC, KS, WN, TXL, TYL>), dim3(grid_x, grid_y, k.ksplit), dim3(256),
                        lds_bytes, st, k);
     return hipGetLastError();
 }
 
-hipError_t ddpm3d_launch_conv_f32(const ConvK& k, const ConvCfg& c, hipStream_t st) {
+hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) {
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     const int gy = (k.CoutPad + 32 * c.WN - 1) / (32 * c.WN);
-#define CASE(KS_, WN_, TXL_, TYL_) \
-    if (c.KS == KS_ && c.WN == WN_ && c.TXL == TXL_ && c.TYL == TYL_) return launch_cfg<KS_, WN_, TXL_, TYL_>(k, gx, gy, st);
-    CASE(3, 4, 3, 3) CASE(3, 2, 3, 3) CASE(3, 1, 3, 3)
-    CASE(3, 4, 2, 2) CASE(3, 2, 2, 2) CASE(3, 1, 2, 2)
-    CASE(1, 4, 3, 3) CASE(1, 2, 3, 3) CASE(1, 1, 3, 3)
-    CASE(1, 4, 2, 2) CASE(1, 2, 2, 2) CASE(1, 1, 2, 2)
+#define CASE(P_, KS_, WN_, TXL_, TYL_)                                                   \
+    if (c.PREC == P_ && c.KS == KS_ && c.WN == WN_ && c.TXL == TXL_ && c.TYL == TYL_)   \
+        return launch_cfg<P_, KS_, WN_, TXL_, TYL_>(k, gx, gy, st);
+    CASE(0, 3, 4, 3, 3) CASE(0, 3, 2, 3, 3) CASE(0, 3, 1, 3, 3)
+    CASE(0, 3, 4, 2, 2) CASE(0, 3, 2, 2, 2) CASE(0, 3, 1, 2, 2)
+    CASE(0, 1, 4, 3, 3) CASE(0, 1, 2, 3, 3) CASE(0, 1, 1, 3, 3)
+    CASE(0, 1, 4, 2, 2) CASE(0, 1, 2, 2, 2) CASE(0, 1, 1, 2, 2)
+    CASE(1, 3, 4, 3, 3) CASE(1, 3, 2, 3, 3) CASE(1, 3, 1, 3, 3)
+    CASE(1, 3, 4, 2, 2) CASE(1, 3, 2, 2, 2) CASE(1, 3, 1, 2, 2)
+    CASE(1, 1, 4, 3, 3) CASE(1, 1, 2, 3, 3) CASE(1, 1, 1, 3, 3)
+    CASE(1, 1, 4, 2, 2) CASE(1, 1, 2, 2, 2) CASE(1, 1, 1, 2, 2)
 #undef CASE
     return hipErrorInvalidValue;
 }

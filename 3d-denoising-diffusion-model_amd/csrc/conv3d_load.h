@@ -1,0 +1,107 @@
+// Shared prologue of the conv kernels: fetch one (halo voxel, 4-channel quad)
+// of the conv's INPUT, i.e. the source tensor(s) seen through the virtual
+// concat, the pool / upsample / planar mode, the GroupNorm(+FiLM) affine and
+// SiLU.  Out-of-bounds voxels are exact zeros (Conv3d zero-pads the tensor
+// AFTER norm+activation).
+#pragma once
+#include "conv3d_params.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// FAST = false: expf + IEEE divide (<= 1 ulp each), for the exact-fp32 path.
+// FAST = true : v_exp_f32 / v_rcp_f32 based (~2 ulp), for the split-f16 path
+//               whose operand representation error is of the same order.
+template <bool FAST>
+__device__ __forceinline__ float silu_f(float v) {
+    if (FAST) return __fdividef(v, 1.0f + __expf(-v));
+    return v / (1.0f + expf(-v));
+}
+
+template <int ACT, bool FAST>
+__device__ __forceinline__ f32x4 affine_act(f32x4 v, f32x4 a, f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float y = fmaf(v[i], a[i], b[i]);
+        r[i] = ACT ? silu_f<FAST>(y) : y;
+    }
+    return r;
+}
+
+struct HaloSrc {
+    const float* src;  // source tensor of this chunk (after the concat split)
+    int Cs;            // its channel count
+    int cb;            // first channel of the chunk inside it
+    int Hs, Ws;        // its H, W
+    bool has_aff;
+    f32x4 ga, gb;      // affine of this thread's quad
+};
+
+template <int CK>
+__device__ __forceinline__ HaloSrc halo_src(const ConvK& p, int n, int chunk, int q) {
+    HaloSrc h;
+    const int c0 = chunk * CK;
+    const bool from0 = c0 < p.C0;
+    h.src = from0 ? p.src0 : p.src1;
+    h.Cs = from0 ? p.C0 : p.C1;
+    h.cb = from0 ? c0 : c0 - p.C0;
+    h.Hs = p.in_mode == DDPM3D_IN_POOL ? 2 * p.H : (p.in_mode == DDPM3D_IN_UP ? p.H / 2 : p.H);
+    h.Ws = p.in_mode == DDPM3D_IN_POOL ? 2 * p.W : (p.in_mode == DDPM3D_IN_UP ? p.W / 2 : p.W);
+    h.has_aff = p.affA != nullptr && p.in_mode != DDPM3D_IN_PLANAR2;
+    h.ga = f32x4{1.f, 1.f, 1.f, 1.f};
+    h.gb = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (h.has_aff) {
+        h.ga = *reinterpret_cast<const f32x4*>(p.affA + (size_t)n * p.Cin + c0 + q * 4);
+        h.gb = *reinterpret_cast<const f32x4*>(p.affB + (size_t)n * p.Cin + c0 + q * 4);
+    }
+    return h;
+}
+
+template <bool FAST>
+__device__ __forceinline__ f32x4 halo_fetch(const ConvK& p, const HaloSrc& h, int n, int z, int y, int x,
+                                            int q, bool first_chunk) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const bool inb = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+    if (!inb) return v;
+    if (p.in_mode == DDPM3D_IN_SAME) {
+        const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
+        v = *reinterpret_cast<const f32x4*>(h.src + vox * h.Cs + h.cb + q * 4);
+        if (h.has_aff) v = p.act ? affine_act<1, FAST>(v, h.ga, h.gb) : affine_act<0, FAST>(v, h.ga, h.gb);
+    } else if (p.in_mode == DDPM3D_IN_UP) {
+        const size_t vox = (((size_t)n * p.D + z) * h.Hs + (y >> 1)) * h.Ws + (x >> 1);
+        v = *reinterpret_cast<const f32x4*>(h.src + vox * h.Cs + h.cb + q * 4);
+        if (h.has_aff) v = p.act ? affine_act<1, FAST>(v, h.ga, h.gb) : affine_act<0, FAST>(v, h.ga, h.gb);
+    } else if (p.in_mode == DDPM3D_IN_POOL) {
+        // AvgPool3d window order (h, w): ((s00 + s01) + s10) + s11, then * 1/4
+        const size_t vox = (((size_t)n * p.D + z) * h.Hs + 2 * y) * h.Ws + 2 * x;
+        const float* b0 = h.src + vox * h.Cs + h.cb + q * 4;
+        f32x4 s00 = *reinterpret_cast<const f32x4*>(b0);
+        f32x4 s01 = *reinterpret_cast<const f32x4*>(b0 + h.Cs);
+        f32x4 s10 = *reinterpret_cast<const f32x4*>(b0 + (size_t)h.Ws * h.Cs);
+        f32x4 s11 = *reinterpret_cast<const f32x4*>(b0 + (size_t)h.Ws * h.Cs + h.Cs);
+        if (h.has_aff) {
+            if (p.act) {
+                s00 = affine_act<1, FAST>(s00, h.ga, h.gb); s01 = affine_act<1, FAST>(s01, h.ga, h.gb);
+                s10 = affine_act<1, FAST>(s10, h.ga, h.gb); s11 = affine_act<1, FAST>(s11, h.ga, h.gb);
+            } else {
+                s00 = affine_act<0, FAST>(s00, h.ga, h.gb); s01 = affine_act<0, FAST>(s01, h.ga, h.gb);
+                s10 = affine_act<0, FAST>(s10, h.ga, h.gb); s11 = affine_act<0, FAST>(s11, h.ga, h.gb);
+            }
+        }
+        v = (((s00 + s01) + s10) + s11) * 0.25f;
+    } else {  // PLANAR2: two single-channel volumes = channels 0 and 1 of the first chunk
+        if (q == 0 && first_chunk) {
+            const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
+            v[0] = p.src0[vox];
+            v[1] = p.src1[vox];
+        }
+    }
+    return v;
+}
+
+// XCD-aware tile order: consecutive tiles (which share halo planes) on one XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}

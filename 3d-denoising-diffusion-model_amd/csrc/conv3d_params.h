@@ -3,9 +3,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include "ddpm3d.h"
 
-#define DDPM3D_CONV_CK 16  // input channels staged per LDS tile
+#define DDPM3D_CONV_CK 16      // input channels staged per LDS tile
+#define DDPM3D_REDUCE_VOX 16   // voxels per workgroup (= per statistics row) of the split-K reduce
+// split-f16 mode: activations are multiplied by this power of two before the hi/lo
+// split, each output channel's weights by 2^floor(log2(W_TARGET / max|w|)); the
+// epilogue multiplies by the exact inverse.  Keeps lo = x - f16(x) a NORMAL f16 for
+// all but negligibly small operands.
+#define DDPM3D_X3_ACT_SCALE 8.0f
+#define DDPM3D_X3_W_TARGET 8.0f
 
 struct ConvK {
     const float* src0;
@@ -17,29 +25,112 @@ struct ConvK {
     const float* res;
     float* out;
     float* stats;
+    float* partial;  // split-K slabs [ksplit][N*D*H*W][Cout], raw accumulators
+    const float* wscale;  // PREC 1: per-cout 1 / (activation scale * weight scale)
     int N, D, H, W, Cin, Cout, C0, C1, CinPad, CoutPad;
     int in_mode, act, bias_stride_n, res_mode, out_layout, stats_rows;
     int tilesX, tilesY, tilesZ;
+    int ksplit, chunks_per_split;
 };
 
 struct ConvCfg {
+    int PREC;      // 0 exact fp32 MFMA, 1 split-f16 (3 MFMA per product)
     int KS;        // 3 or 1
     int WN;        // waves along Cout (4, 2, 1); waves along voxels = 4 / WN
     int TXL, TYL;  // log2 of the tile extent in W and H; tile depth = 128 >> (TXL+TYL)
+    int S;         // split-K factor over the Cin chunks (1 = none)
+    int tilesX, tilesY, tilesZ;
+    int stats_rows;           // rows per sample the executing path writes
+    size_t workspace_bytes;   // slabs needed when S > 1
 };
 
 static inline int ddpm3d_round_up(int v, int m) { return (v + m - 1) / m * m; }
-
-// One rule, used by the launcher, by ddpm3d_conv_stats_rows and by the weight
-// packer (CoutPad / CinPad): how a conv of this shape is tiled.
-static inline ConvCfg ddpm3d_conv_cfg(int H, int W, int Cout, int ksize) {
-    ConvCfg c;
-    c.KS = ksize;
-    c.WN = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
-    if (H >= 8 && W >= 8) { c.TXL = 3; c.TYL = 3; } else { c.TXL = 2; c.TYL = 2; }
-    return c;
-}
 static inline int ddpm3d_cout_pad(int Cout) { return ddpm3d_round_up(Cout, 32); }
 static inline int ddpm3d_cin_pad(int Cin) { return ddpm3d_round_up(Cin, DDPM3D_CONV_CK); }
 
-hipError_t ddpm3d_launch_conv_f32(const ConvK& k, const ConvCfg& c, hipStream_t st);
+// One rule, used by the launcher, by ddpm3d_conv_stats_rows /
+// ddpm3d_conv_workspace_bytes and by the weight packer: how a conv of this
+// shape is tiled and whether its reduction dimension is split over workgroups.
+//
+// Split-K: a low-resolution level has few 128-voxel tiles (64x4x4 -> 8), so
+// without it a 512->512 conv occupies 32 of 256 CUs.  The Cin chunks are dealt
+// to S workgroups per tile; the cost model below is (workgroups on the busiest
+// CU) x (chunks per workgroup + fixed cost) / (MFMA efficiency at that
+// co-residency), efficiencies measured on MI355X with the unsplit kernel.
+static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int Cout, int ksize) {
+    ConvCfg c;
+    c.PREC = 0;  // set by the caller from the descriptor
+    c.KS = ksize;
+    c.WN = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
+    if (H >= 8 && W >= 8) { c.TXL = 3; c.TYL = 3; } else { c.TXL = 2; c.TYL = 2; }
+    const int TX = 1 << c.TXL, TY = 1 << c.TYL, TZ = 128 / (TX * TY);
+    c.tilesX = (W + TX - 1) / TX;
+    c.tilesY = (H + TY - 1) / TY;
+    c.tilesZ = (D + TZ - 1) / TZ;
+    const long long mtiles = (long long)N * c.tilesZ * c.tilesY * c.tilesX;
+    const long long blocks = mtiles * ((ddpm3d_cout_pad(Cout) + 32 * c.WN - 1) / (32 * c.WN));
+    const int nch = ddpm3d_cin_pad(Cin) / DDPM3D_CONV_CK;
+    int best = 1;
+    if (ksize == 3 && c.WN == 4) {
+        const char* force = getenv("DDPM3D_KSPLIT");
+        if (force) {
+            best = atoi(force);
+            if (best < 1) best = 1;
+            if (best > nch) best = nch;
+        } else {
+            static const double eff[4] = {1.0, 0.62, 0.78, 0.82};
+            double best_cost = 1e300;
+            for (int s = 1; s <= 32 && s <= nch; ++s) {
+                const int cps = (nch + s - 1) / s;
+                if (s > 1 && cps < 2) break;
+                const long long per_cu = (blocks * s + 255) / 256;
+                const double e = eff[per_cu > 3 ? 3 : (int)per_cu];
+                const double cost = (double)per_cu * (cps + (s > 1 ? 0.75 : 0.5)) / e;
+                if (cost < best_cost * 0.97) { best_cost = cost; best = s; }
+            }
+        }
+    }
+    c.S = best;
+    const long long vox = (long long)D * H * W;
+    if (c.S > 1) {
+        c.stats_rows = (int)((vox + DDPM3D_REDUCE_VOX - 1) / DDPM3D_REDUCE_VOX);
+        c.workspace_bytes = (size_t)c.S * N * vox * Cout * sizeof(float);
+    } else {
+        c.stats_rows = c.tilesZ * c.tilesY * c.tilesX * (4 / c.WN);
+        c.workspace_bytes = 0;
+    }
+    return c;
+}
+
+// bytes of the packed weight image: fp32 [tap][ci/8][CoutPad][8] for PREC 0;
+// f16 [tap][ci/16][hi|lo][CoutPad][16] followed by CoutPad fp32 output scales for PREC 1
+static inline size_t ddpm3d_packed_bytes(int Cout, int Cin, int ksize, int prec) {
+    const size_t body = (size_t)ksize * ksize * ksize * ddpm3d_cin_pad(Cin) * ddpm3d_cout_pad(Cout) * 4;
+    return prec == 1 ? body + (size_t)ddpm3d_cout_pad(Cout) * 4 : body;
+}
+
+hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st);
+hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st);
+
+// Residual term of the conv epilogue for output element (n, z, y, x, cout);
+// shared by the conv kernel and the split-K reduce kernel.
+__device__ __forceinline__ float ddpm3d_residual(const ConvK& p, int n, int z, int y, int x, int cout) {
+    if (p.res_mode == DDPM3D_RES_SAME) {
+        const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
+        return p.res[vox * p.Cout + cout];
+    }
+    if (p.res_mode == DDPM3D_RES_UP) {
+        const int Hr = p.H / 2, Wr = p.W / 2;
+        const size_t rv = (((size_t)n * p.D + z) * Hr + (y >> 1)) * Wr + (x >> 1);
+        return p.res[rv * p.Cout + cout];
+    }
+    if (p.res_mode == DDPM3D_RES_POOL) {
+        // AvgPool3d window order (h, w): ((r00 + r01) + r10) + r11, then * 1/4
+        const int Hr = p.H * 2, Wr = p.W * 2;
+        const size_t rv = (((size_t)n * p.D + z) * Hr + 2 * y) * Wr + 2 * x;
+        const float* r0 = p.res + rv * p.Cout + cout;
+        const float r = ((r0[0] + r0[p.Cout]) + r0[(size_t)Wr * p.Cout]) + r0[(size_t)Wr * p.Cout + p.Cout];
+        return r * 0.25f;
+    }
+    return 0.0f;
+}

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, float* out, hipStream_t st);
+hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, int prec, void* out, hipStream_t st);
 hipError_t ddpm3d_launch_gn_finalize(const float* st0, int C0, int rows0, const float* st1, int C1,
                                      int rows1, int N, int groups, double count, float eps,
                                      const float* gamma, const float* beta, const float* film,

@@ -26,14 +26,70 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Ci
     }
 }
 
-hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, float* out, hipStream_t st) {
+// Split-f16 image.  Pass 1: per output channel, the power-of-two scale
+// s = 2^floor(log2(W_TARGET / max|w|)) and the epilogue factor 1 / (ACT_SCALE * s).
+__global__ __launch_bounds__(256) void pack_x3_scale_kernel(const float* __restrict__ w, int Cout, int per_cout,
+                                                            float* __restrict__ wscale) {
+    const int co = blockIdx.x;
+    float m = 0.0f;
+    if (co < Cout)
+        for (int i = threadIdx.x; i < per_cout; i += 256) m = fmaxf(m, fabsf(w[(size_t)co * per_cout + i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float s = 1.0f;
+        if (m > 0.0f && m < 3.0e38f) s = exp2f(floorf(log2f(DDPM3D_X3_W_TARGET / m)));
+        s = fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
+        wscale[co] = 1.0f / (DDPM3D_X3_ACT_SCALE * s);  // exact: powers of two
+    }
+}
+
+// Pass 2: OIDHW -> [tap][ci/16][hi|lo][CoutPad][16 f16] of w * s[cout] (zero padded),
+// with s = 1 / (ACT_SCALE * wscale[cout]) recovered exactly from pass 1's output.
+__global__ void pack_x3_kernel(const float* __restrict__ w, const float* __restrict__ wscale, int Cout,
+                               int Cin, int taps, int CoutPad, int CinPad, _Float16* __restrict__ out) {
+    const size_t total = (size_t)taps * CinPad * CoutPad;  // one (hi, lo) pair per element
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 15);
+        size_t r = i >> 4;
+        const int co = (int)(r % CoutPad); r /= CoutPad;
+        const int cb = (int)(r % (CinPad / 16));
+        const int tap = (int)(r / (CinPad / 16));
+        const int ci = cb * 16 + j;
+        float v = 0.0f;
+        if (co < Cout && ci < Cin)
+            v = w[((size_t)co * Cin + ci) * taps + tap] * (1.0f / (DDPM3D_X3_ACT_SCALE * wscale[co]));
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const size_t base = (((size_t)tap * (CinPad / 16) + cb) * 2) * CoutPad * 16;
+        out[base + (size_t)co * 16 + j] = hi;
+        out[base + (size_t)CoutPad * 16 + (size_t)co * 16 + j] = lo;
+    }
+}
+
+hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, int prec, void* out, hipStream_t st) {
     const int taps = ks * ks * ks;
     const int CoutPad = ddpm3d_cout_pad(Cout), CinPad = ddpm3d_cin_pad(Cin);
     const size_t total = (size_t)taps * CinPad * CoutPad;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w, Cout, Cin, taps, CoutPad,
-                       CinPad, out);
+    if (prec == 0) {
+        hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st, w, Cout, Cin, taps, CoutPad,
+                           CinPad, (float*)out);
+        return hipGetLastError();
+    }
+    // PREC 1: [f16 image (total hi/lo pairs = total*4 bytes)][CoutPad fp32 wscale]
+    float* wscale = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + total * 4);
+    hipLaunchKernelGGL(pack_x3_scale_kernel, dim3(CoutPad), dim3(256), 0, st, w, Cout, Cin * taps, wscale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pack_x3_kernel, dim3(blocks), dim3(256), 0, st, w, wscale, Cout, Cin, taps, CoutPad,
+                       CinPad, (_Float16*)out);
     return hipGetLastError();
 }
 

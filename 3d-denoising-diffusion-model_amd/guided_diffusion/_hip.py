@@ -20,7 +20,9 @@ ACT_NONE, ACT_SILU = 0, 1
 OUT_NDHWC, OUT_NCDHW = 0, 1
 F_LEARN_SIGMA, F_PREDICT_XSTART, F_CLIP = 1, 2, 4
 NCOEF = 8
-ABI_VERSION = 1
+PREC_F32, PREC_F16X3 = 0, 1
+PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3}
+ABI_VERSION = 3
 
 _fp = C.c_void_p
 
@@ -34,7 +36,7 @@ class ConvDesc(C.Structure):
         ("aff_a", _fp), ("aff_b", _fp), ("act", C.c_int32), ("precision", C.c_int32),
         ("w_packed", _fp), ("bias", _fp), ("bias_stride_n", C.c_int32), ("res_mode", C.c_int32),
         ("res", _fp), ("out", _fp), ("out_layout", C.c_int32), ("stats_rows", C.c_int32),
-        ("stats", _fp),
+        ("stats", _fp), ("workspace", _fp), ("workspace_bytes", C.c_size_t),
     ]
 
 
@@ -42,9 +44,10 @@ EXPORTS = {
     # name: (restype, argtypes)
     "ddpm3d_abi_version": (C.c_int, []),
     "ddpm3d_last_error": (C.c_char_p, []),
-    "ddpm3d_packed_weight_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    "ddpm3d_pack_conv_weight": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
-    "ddpm3d_conv_stats_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ddpm3d_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ddpm3d_pack_conv_weight": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ddpm3d_conv_stats_rows": (C.c_int, [C.c_int] * 7),
+    "ddpm3d_conv_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "ddpm3d_conv3d": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "ddpm3d_gn_finalize": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),

@@ -39,25 +39,31 @@ class Act:
 
 
 class PackedConv:
-    __slots__ = ("w", "b", "Cout", "Cin", "k")
+    __slots__ = ("w", "b", "Cout", "Cin", "k", "precision")
 
-    def __init__(self, weight, bias, stream):
+    def __init__(self, weight, bias, precision, stream):
         lib = H.load()
         Cout, Cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
-        n = lib.ddpm3d_packed_weight_elems(Cout, Cin, k)
+        n = lib.ddpm3d_packed_weight_bytes(Cout, Cin, k, precision)
         if n == 0:
             raise RuntimeError("unsupported conv weight shape %s" % (tuple(weight.shape),))
         w32 = weight.detach().float().contiguous()
-        self.w = torch.empty(n, dtype=torch.float32, device=weight.device)
-        H.check(lib.ddpm3d_pack_conv_weight(H.ptr(w32), Cout, Cin, k, H.ptr(self.w), stream))
+        self.w = torch.empty(n, dtype=torch.uint8, device=weight.device)
+        H.check(lib.ddpm3d_pack_conv_weight(H.ptr(w32), Cout, Cin, k, precision, H.ptr(self.w), stream))
         self.b = bias.detach().float().contiguous()
-        self.Cout, self.Cin, self.k = Cout, Cin, k
+        self.Cout, self.Cin, self.k, self.precision = Cout, Cin, k, precision
 
 
 class UNetEngine:
     """Executes one model on one device.  `layers` is unet.py's topology."""
 
-    def __init__(self, topo, params, model_channels, film, device):
+    def __init__(self, topo, params, model_channels, film, device, precision="f32"):
+        """precision: "f32" = exact fp32 MFMA everywhere; "f16x3" = the 3x3x3 convs
+        evaluate each fp32 product as three f16 MFMAs (fp32-equivalent accuracy, see
+        include/ddpm3d.h); 1x1x1 convs (HBM-bound) stay on the exact path."""
+        if precision not in H.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(H.PRECISIONS))
+        self.precision = precision
         self.lib = H.load()
         self.topo = topo
         self.device = device
@@ -71,7 +77,8 @@ class UNetEngine:
             if name.endswith(".weight") and t.dim() >= 3:
                 base = name[:-len(".weight")]
                 w = t if t.dim() == 5 else t.reshape(t.shape[0], t.shape[1], 1, 1, 1)
-                self.conv[base] = PackedConv(w, params[base + ".bias"], st)
+                prec = H.PRECISIONS[precision] if w.shape[2] == 3 else H.PREC_F32
+                self.conv[base] = PackedConv(w, params[base + ".bias"], prec, st)
         # fuse every ResBlock's emb_layers Linear into one [total, ted] matrix
         ws, bs, self.film_off = [], [], {}
         off = 0
@@ -150,13 +157,16 @@ class _Plan:
         topo = eng.topo
         lib = eng.lib
 
-        def new_act(Cn, d, h, w, ks=3, stats=True):
+        def new_act(Cn, d, h, w):
+            # the statistics buffer is attached by the conv step that produces the tensor
+            # (its row count depends on how that conv is tiled / split)
             buf = torch.empty(N * d * h * w * Cn, dtype=torch.float32, device=dev)
-            rows = lib.ddpm3d_conv_stats_rows(d, h, w, Cn, ks)
-            stt = torch.empty(N * rows * Cn * 2, dtype=torch.float32, device=dev) if stats else None
-            act = Act(buf, Cn, d, h, w, stt, rows)
+            act = Act(buf, Cn, d, h, w, None, 0)
             self.keep.append(act)  # descriptors hold raw pointers: the plan owns every buffer
             return act
+
+        self.ws_descs = []      # conv descriptors that need the shared split-K workspace
+        self.ws_bytes = 0
 
         self.new_act = new_act
         first = topo.input[0][0]
@@ -185,6 +195,11 @@ class _Plan:
         self.out_buf = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
         self.last_desc = self.conv_step(oc, srcs=[h], out=None, aff=(A, B), act=H.ACT_SILU,
                                         out_tensor=self.out_buf, out_layout=H.OUT_NCDHW)
+        # one split-K scratch buffer shared by every conv of the plan (they run in stream order)
+        if self.ws_bytes:
+            self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+            for dsc in self.ws_descs:
+                dsc.workspace, dsc.workspace_bytes = H.ptr(self.workspace), self.ws_bytes
 
     # ---- helpers -------------------------------------------------------------
     def finalize(self, srcs, gn_prefix, film_prefix):
@@ -215,11 +230,16 @@ class _Plan:
                   bias_per_n=False, want_stats=True):
         N = self.N
         d = H.ConvDesc()
+        lib = self.eng.lib
+        cin_total = 2 if planar else sum(s.C for s in srcs)
         if out is not None:
             d.N, d.D, d.H, d.W = N, out.D, out.H, out.W
             d.out = H.ptr(out.buf)
-            d.stats = H.ptr(out.stats) if want_stats else 0
-            d.stats_rows = out.rows if want_stats else 0
+            if want_stats:
+                out.rows = lib.ddpm3d_conv_stats_rows(N, out.D, out.H, out.W, cin_total, pc.Cout, pc.k)
+                out.stats = torch.empty(N * out.rows * pc.Cout * 2, dtype=torch.float32,
+                                        device=self.eng.device)
+                d.stats, d.stats_rows = H.ptr(out.stats), out.rows
         else:
             s = srcs[0]
             d.N, d.D, d.H, d.W = N, s.D, s.H, s.W
@@ -241,17 +261,22 @@ class _Plan:
         if aff is not None:
             d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
         d.act = act
+        d.precision = pc.precision
         d.w_packed, d.bias = H.ptr(pc.w), H.ptr(pc.b)
         d.bias_stride_n = 0  # per-sample bias rows are patched in run()
         d.res_mode = res_mode
         d.res = H.ptr(res.buf) if res is not None else 0
+        need = lib.ddpm3d_conv_workspace_bytes(N, d.D, d.H, d.W, d.Cin, pc.Cout, pc.k)
+        if need:
+            self.ws_descs.append(d)
+            self.ws_bytes = max(self.ws_bytes, need)
         self.keep.append(d)
         # bookkeeping for measurement: algorithmic FLOPs (2 per MAC) and the kernel
         # instantiation the C side picks for this shape (conv3d_params.h rule)
         wn = 4 if pc.Cout > 64 else (2 if pc.Cout > 32 else 1)
         tile = 8 if (d.H >= 8 and d.W >= 8) else 4
         flops = 2.0 * N * d.D * d.H * d.W * pc.Cout * d.Cin * pc.k ** 3
-        self.conv_meta[len(self.steps)] = ("conv3d_k%d_wn%d_t%d" % (pc.k, wn, tile), flops)
+        self.conv_meta[len(self.steps)] = ("conv3d_p%d_k%d_wn%d_t%d" % (pc.precision, pc.k, wn, tile), flops)
         self.steps.append((self.eng.lib.ddpm3d_conv3d, [C.byref(d), 0]))
         return d
 

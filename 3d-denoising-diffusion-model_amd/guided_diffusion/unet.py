@@ -17,6 +17,7 @@ What is different: no module here computes anything with ATen.  The layer
 list is flattened into `Topology`, and `forward` hands x to UNetEngine.
 """
 
+import os
 import warnings
 from collections import namedtuple
 
@@ -221,6 +222,9 @@ class UNetModel_noatt(nn.Module):
                                  _zero(nn.Conv3d(t.input_ch, out_channels, 3, padding=1)))
         self._engine = None
         self._engine_key = None
+        # arithmetic of the 3x3x3 convolutions' products: "f32" (exact fp32 MFMA) or
+        # "f16x3" (fp32 emulated by three f16 MFMAs; fp32-equivalent accuracy)
+        self.conv_precision = os.environ.get("DDPM3D_PRECISION", "f32")
 
     # ---- precision switches (unet.py:999-1013) -------------------------------
     def convert_to_fp16(self):
@@ -240,12 +244,12 @@ class UNetModel_noatt(nn.Module):
         if not p0.is_cuda:
             raise RuntimeError("model parameters are on %s: move the model to the GPU (model.to('cuda')); "
                                "this package has no CPU path" % p0.device)
-        key = self._params_key()
+        key = (self.conv_precision,) + self._params_key()
         if self._engine is None or self._engine_key != key:
             params = {k: v.detach().float().contiguous() for k, v in self.state_dict().items()}
             with torch.cuda.device(p0.device):
                 self._engine = UNetEngine(self.topology, params, self.model_channels,
-                                          self.use_scale_shift_norm, p0.device)
+                                          self.use_scale_shift_norm, p0.device, self.conv_precision)
             self._engine_key = key
         return self._engine
 

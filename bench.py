@@ -42,6 +42,7 @@ PUBLISHED = dict(large_size=96, small_size=96, num_channels=128, num_res_blocks=
                  use_scale_shift_norm=True)
 TINY = dict(PUBLISHED, num_channels=32, num_res_blocks=1)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: f16/bf16 MFMA, dense
 
 
 def log(*a):
@@ -105,6 +106,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
     ap.add_argument("--arch", choices=["published", "tiny"], default="published")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for cpu_baseline")
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default=os.environ.get("DDPM3D_PRECISION", "f32"),
+                    help="arithmetic of the 3x3x3 conv products (both keep fp32 data and accumulators)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +128,10 @@ def main():
     arch = PUBLISHED if args.arch == "published" else TINY
     respacing = str(args.ddpm_steps)
     model, diff, sd = build_model(arch, respacing, device)
+    model.conv_precision = args.precision
+    # roofline peak for the dominant kernel's arithmetic: fp32 MFMA, or f16 MFMA / 3
+    # (three f16 MFMAs per algorithmic fp32 product)
+    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
     B, S = args.batch, args.size
     shape = (B, 1, S, S, S)
     lr = torch.from_numpy(np.stack([synth.synth_low_res((1, S, S, S), seed=1234 + rank * 1000 + b)
@@ -196,8 +204,10 @@ def main():
         tag, (cnt, fl, ms) = dom
         ach = fl / (ms * 1e-3) / 1e12
         roof = {
-            "bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": round(peak, 1),
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "peak_basis": ("fp32 MFMA dense" if args.precision == "f32" else
+                           "f16 MFMA dense (2500) / 3 MFMAs per algorithmic fp32 product"),
             "launches_timed": cnt, "avg_launch_ms": round(ms / cnt, 4),
             "all_conv_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                  "ms_per_forward": round(tot_ms / max(1, args.steps), 3),
@@ -226,7 +236,10 @@ def main():
                                    "learn_sigma), seeded random weights, device RNG"
                                    % (B, S, T, args.arch, arch["num_channels"], arch["num_res_blocks"]),
                        "parallelism": "independent volumes per rank (dp%d), all_gather of finished samples" % world,
-                       "tflop_per_volume": round(flops_fwd * T / B / 1e12, 1)},
+                       "tflop_per_volume": round(flops_fwd * T / B / 1e12, 1),
+                       "conv_arithmetic": ("exact fp32 MFMA" if args.precision == "f32" else
+                                           "fp32 data/accumulators; each product of the 3x3x3 convs = 3 f16 "
+                                           "MFMAs on hi/lo-split operands (error below fp32 accumulation error)")},
             "roofline": roof,
         }
         if world == 1 and args.cpu_steps > 0:
@@ -235,6 +248,9 @@ def main():
                 threads = len(os.sched_getaffinity(0))
             except Exception:
                 pass
+            # a one-GPU box exposes every host core but grants a 16-core share; more
+            # threads than that only thrash (measured: 87 s/step at 256 threads)
+            threads = min(threads, args.cpu_threads)
             sd_cpu = {k: v for k, v in sd.items()}
             res["cpu_baseline"] = cpu_baseline(arch, sd_cpu, S, respacing, args.cpu_steps, threads)
         else:

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DDPM3D_ABI_VERSION 1
+#define DDPM3D_ABI_VERSION 3
 
 enum {
     DDPM3D_OK = 0,
@@ -96,11 +96,11 @@ typedef struct ddpm3d_conv_desc {
     const float* aff_a;     /* [N][Cin]                                              */
     const float* aff_b;     /* [N][Cin]                                              */
     int32_t act;            /* DDPM3D_ACT_*                                          */
-    int32_t precision;      /* 0 = exact fp32 MFMA; others reserved                  */
+    int32_t precision;      /* DDPM3D_PREC_* (must match how w_packed was packed)    */
     /* weights in the layout ddpm3d_pack_conv_weight produces; bias [Cout]
      * (bias_stride_n = 0), or one row of Cout values per sample, rows
      * bias_stride_n floats apart (additive timestep embedding, unet.py:254-255) */
-    const float* w_packed;
+    const void* w_packed;
     const float* bias;
     int32_t bias_stride_n;
     int32_t res_mode;       /* DDPM3D_RES_*                                          */
@@ -109,20 +109,36 @@ typedef struct ddpm3d_conv_desc {
     int32_t out_layout;     /* DDPM3D_OUT_*                                          */
     int32_t stats_rows;     /* rows per sample of `stats` (from ddpm3d_conv_stats_rows) */
     float* stats;           /* [N][stats_rows][Cout][2] or NULL                      */
+    /* scratch for split-K partial sums (low-resolution levels, where the voxel
+     * tiles alone cannot fill 256 CUs); >= ddpm3d_conv_workspace_bytes(...) bytes,
+     * may be shared by all convs of a stream, NULL when that query returns 0 */
+    void* workspace;
+    size_t workspace_bytes;
 } ddpm3d_conv_desc;
 
 int ddpm3d_abi_version(void);
 const char* ddpm3d_last_error(void);
 
-/* number of fp32 elements of the packed form of an (Cout, Cin, k, k, k) weight */
-size_t ddpm3d_packed_weight_elems(int Cout, int Cin, int ksize);
-/* OIDHW (torch Conv3d.weight / Conv1d.weight with k=1) -> packed; device to device */
-int ddpm3d_pack_conv_weight(const float* w_oidhw, int Cout, int Cin, int ksize,
-                            float* w_packed, void* stream);
+/* Arithmetic of the convolution's products.  Inputs, outputs and accumulators are
+ * fp32 in both modes.
+ *   DDPM3D_PREC_F32    v_mfma_f32_32x32x2_f32: exact fp32 products.
+ *   DDPM3D_PREC_F16X3  every fp32 operand x is split hi + lo into two f16 (after a
+ *                      power-of-two scaling) and a*b = hi*hi + hi*lo + lo*hi on
+ *                      v_mfma_f32_32x32x16_f16 (each f16xf16 product is exact in
+ *                      fp32).  Operand representation error ~2^-23, i.e. below the
+ *                      fp32 accumulation error both modes share; 16/3 the MFMA rate. */
+enum { DDPM3D_PREC_F32 = 0, DDPM3D_PREC_F16X3 = 1 };
 
-/* rows per sample of the statistics buffer a conv over (D,H,W) with Cout
- * outputs writes */
-int ddpm3d_conv_stats_rows(int D, int H, int W, int Cout, int ksize);
+/* bytes of the packed form of an (Cout, Cin, k, k, k) weight for a precision mode */
+size_t ddpm3d_packed_weight_bytes(int Cout, int Cin, int ksize, int precision);
+/* OIDHW (torch Conv3d.weight / Conv1d.weight with k=1) -> packed; device to device */
+int ddpm3d_pack_conv_weight(const float* w_oidhw, int Cout, int Cin, int ksize, int precision,
+                            void* w_packed, void* stream);
+
+/* rows per sample of the statistics buffer this conv writes, and the scratch
+ * it needs (both depend on how the shape is tiled / split) */
+int ddpm3d_conv_stats_rows(int N, int D, int H, int W, int Cin, int Cout, int ksize);
+size_t ddpm3d_conv_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int ksize);
 int ddpm3d_conv3d(const ddpm3d_conv_desc* desc, void* stream);
 
 /*

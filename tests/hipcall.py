@@ -16,16 +16,18 @@ def to_ncdhw(x):
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
-def pack(w):
+def pack(w, precision=0):
     lib = H.load()
     co, ci, k = w.shape[0], w.shape[1], w.shape[2]
-    out = torch.empty(lib.ddpm3d_packed_weight_elems(co, ci, k), dtype=torch.float32, device=w.device)
-    H.check(lib.ddpm3d_pack_conv_weight(H.ptr(w.contiguous()), co, ci, k, H.ptr(out), H.stream()))
+    out = torch.empty(lib.ddpm3d_packed_weight_bytes(co, ci, k, precision), dtype=torch.uint8, device=w.device)
+    wc = w.contiguous()
+    H.check(lib.ddpm3d_pack_conv_weight(H.ptr(wc), co, ci, k, precision, H.ptr(out), H.stream()))
+    torch.cuda.synchronize()
     return out
 
 
 def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res=None, res_mode=H.RES_NONE,
-           out_layout=H.OUT_NDHWC, want_stats=True, planar=False, bias_stride_n=0):
+           out_layout=H.OUT_NDHWC, want_stats=True, planar=False, bias_stride_n=0, precision=0):
     """srcs: list of NDHWC device tensors (or two (N,1,D,H,W) volumes when planar).
     Returns (out, stats, rows)."""
     lib = H.load()
@@ -48,7 +50,8 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
     if aff is not None:
         d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
     d.act = act
-    wp = pack(w)
+    d.precision = precision
+    wp = pack(w, precision)
     d.w_packed, d.bias, d.bias_stride_n = H.ptr(wp), H.ptr(b), bias_stride_n
     d.res_mode, d.res = res_mode, H.ptr(res)
     if out_layout == H.OUT_NDHWC:
@@ -56,7 +59,11 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
     else:
         out = torch.full((N, co, D, Hh, W), float("nan"), dtype=torch.float32, device=dev)
     d.out, d.out_layout = H.ptr(out), out_layout
-    rows = lib.ddpm3d_conv_stats_rows(D, Hh, W, co, k)
+    rows = lib.ddpm3d_conv_stats_rows(N, D, Hh, W, ci, co, k)
+    need = lib.ddpm3d_conv_workspace_bytes(N, D, Hh, W, ci, co, k)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    if need:
+        d.workspace, d.workspace_bytes = H.ptr(ws), need
     stats = None
     if want_stats and out_layout == H.OUT_NDHWC:
         stats = torch.full((N, rows, co, 2), float("nan"), dtype=torch.float32, device=dev)

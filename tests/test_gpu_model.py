@@ -23,11 +23,13 @@ PUBLISHED = dict(large_size=96, small_size=96, num_channels=128, num_res_blocks=
 TINY = dict(PUBLISHED, num_channels=32, num_res_blocks=1)
 
 
-def build(over, resp=""):
+def build(over, resp="", precision=None):
     fl = su.sr_model_and_diffusion_defaults()
     fl.update(over)
     fl["timestep_respacing"] = resp
     model, diff = su.sr_create_model_and_diffusion(**fl)
+    if precision is not None:
+        model.conv_precision = precision
     sd = model.state_dict()
     model.load_state_dict({k: torch.from_numpy(synth.synth_param(k, tuple(v.shape))) for k, v in sd.items()})
     model.to("cuda").eval()
@@ -58,10 +60,12 @@ def test_unet_forward_vs_reference_golden(golden, tag, over, shape, t):
     assert rel_err(y.cpu().numpy(), ref) < 1e-4, tag
 
 
-def test_unet_forward_published_architecture(golden):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_unet_forward_published_architecture(golden, precision):
     """206 964 610-parameter network with mult (1,1,2,3,4) / 2 res blocks, at 1x1x8x32x32:
-    pins the decoder's channel bookkeeping and every tile configuration it uses."""
-    model, _ = build(PUBLISHED)
+    pins the decoder's channel bookkeeping and every tile configuration it uses, in both
+    arithmetic modes of the 3x3x3 convolutions at the same tolerance."""
+    model, _ = build(PUBLISHED, precision=precision)
     x, lr = inputs((1, 1, 8, 32, 32))
     with torch.no_grad():
         y = model(x.cuda(), torch.tensor([251]).cuda(), low_res=lr.cuda())
@@ -110,6 +114,16 @@ def test_sampler_loops_vs_reference_golden(golden, tag, over, shape, resp, kind,
     g = golden("sampler.npz")
     assert rel_err(last["sample"].cpu().numpy(), g[tag + "/sample"]) < 1e-3, tag
     assert np.allclose(np.array(trace), g[tag + "/trace"], rtol=1e-3, atol=1e-4)
+
+
+def test_sampler_loop_f16x3_vs_reference_golden(golden):
+    """BASELINE config 1 end to end with the 3x3x3 convs in split-f16 mode: same 1e-3 bar."""
+    model, diff = build(TINY, "10", precision="f16x3")
+    shape = (1, 1, 32, 32, 32)
+    draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, 11, seed=10)]
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234)).cuda()
+    out = diff.p_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
+    assert rel_err(out.cpu().numpy(), golden("sampler.npz")["ddpm10_32/sample"]) < 1e-3
 
 
 def test_p_sample_loop_api_and_determinism():

@@ -49,28 +49,58 @@ def check_stats(stats, y_ncdhw):
     (1, 9, 4, 4, 32, 96),      # 4x4 tiles (low-resolution levels), partial D tile, idle wave
     (1, 2, 2, 2, 16, 160),     # H,W below the tile, two cout blocks
     (1, 2, 6, 6, 32, 64),      # 96^3-patch style non-power-of-two H,W on 4x4 tiles
+    (1, 16, 4, 4, 128, 128),   # low-resolution level: split-K over Cin + reduce kernel
+    (2, 9, 8, 8, 96, 160),     # split-K with a ragged D tile, two cout blocks, batch 2
+    (1, 64, 4, 4, 512, 384),   # the published net's 4x4 level shape (16-way split)
 ])
-def test_conv3d_k3_plain(hc, N, D, Hh, W, ci, co):
+@pytest.mark.parametrize("precision", [0, 1])
+def test_conv3d_k3_plain(hc, N, D, Hh, W, ci, co, precision):
+    """precision 0 = exact fp32 MFMA; 1 = fp32 products as three f16 MFMAs.  Same tolerance:
+    the split's operand error (~2^-23) is below the fp32 accumulation error both share."""
     x = rnd(N, ci, D, Hh, W, seed=1)
     w = rnd(co, ci, 3, 3, 3, seed=2, scale=0.05)
     b = rnd(co, seed=3)
     ref = F.conv3d(x, w, b, padding=1)
-    out, stats, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (D, Hh, W))
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (D, Hh, W), precision=precision)
     got = hc.to_ncdhw(out.cpu())
     assert rel_err(got.numpy(), ref.numpy()) < TOL
     check_stats(stats, ref)
 
 
-def test_conv3d_exact_integer_mapping(hc):
-    """Small-integer data makes every product and sum exact: any wrong tap, channel
-    permutation or row/column swap shows up as a mismatch, not as rounding."""
+@pytest.mark.parametrize("precision", [0, 1])
+def test_conv3d_exact_integer_mapping(hc, precision):
+    """Small-integer data makes every product and sum exact (in the split-f16 mode too: the
+    scaled integers are exact f16 with lo = 0): any wrong tap, channel permutation or
+    row/column swap shows up as a mismatch, not as rounding."""
     g = np.random.default_rng(5)
     x = torch.from_numpy(g.integers(-3, 4, (1, 16, 3, 9, 10)).astype(np.float32))
     w = torch.from_numpy(g.integers(-2, 3, (40, 16, 3, 3, 3)).astype(np.float32))
     b = torch.from_numpy(g.integers(-5, 6, (40,)).astype(np.float32))
     ref = F.conv3d(x, w, b, padding=1)
-    out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (3, 9, 10))
+    out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (3, 9, 10), precision=precision)
     assert torch.equal(hc.to_ncdhw(out.cpu()), ref)
+
+
+def test_conv3d_f16x3_accuracy_is_fp32_grade(hc):
+    """Against an fp64 reference, the split-f16 mode must be as accurate as the exact fp32
+    mode (within 2x), on a K = 27*256 reduction with realistic operand ranges, including
+    tiny weights / activations whose f16 low parts would be subnormal without the scaling."""
+    x = rnd(1, 256, 4, 16, 16, seed=11)
+    x = (x / (1 + torch.exp(-x)))                     # post-SiLU range
+    x[:, :32] *= 1e-3                                  # some very small activations
+    w = rnd(128, 256, 3, 3, 3, seed=12, scale=0.01)
+    w[:16] *= 1e-3                                     # some very small output channels
+    b = rnd(128, seed=13)
+    ref = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    errs = []
+    for precision in (0, 1):
+        out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (4, 16, 16), precision=precision)
+        got = hc.to_ncdhw(out.cpu()).double()
+        # per-output-channel relative error (small channels must not drown in the big ones)
+        e = ((got - ref).abs().amax(dim=(0, 2, 3, 4)) / ref.abs().amax(dim=(0, 2, 3, 4))).max()
+        errs.append(float(e))
+    assert errs[0] < 2e-6 and errs[1] < 2e-6, errs
+    assert errs[1] < 2 * errs[0] + 2e-7, errs
 
 
 def test_conv3d_k1_concat(hc):
@@ -169,6 +199,25 @@ def test_conv3d_downsample_block_paths(hc):
     xd = hc.to_ndhwc(x).cuda()
     A, B = _gn_affine(hc, [x], gamma, beta)
     out, stats, _ = hc.conv3d([xd], w.cuda(), b.cuda(), (3, 8, 6), in_mode=H.IN_POOL, aff=(A, B),
+                              act=H.ACT_SILU, res=xd, res_mode=H.RES_POOL)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)
+
+
+def test_conv3d_splitk_with_pooled_paths(hc):
+    """Split-K path with the prologue pool, the pooled residual and statistics from the reduce kernel."""
+    import guided_diffusion._hip as H
+    lib = H.load()
+    assert lib.ddpm3d_conv_workspace_bytes(1, 12, 4, 4, 128, 128, 3) > 0   # this shape does split
+    x = rnd(1, 128, 12, 8, 8, seed=1)
+    gamma, beta = 1 + 0.1 * rnd(128, seed=3), 0.1 * rnd(128, seed=4)
+    w = rnd(128, 128, 3, 3, 3, seed=2, scale=0.03)
+    b = rnd(128, seed=5)
+    pool = lambda t: F.avg_pool3d(t, (1, 2, 2), (1, 2, 2))
+    ref = F.conv3d(pool(F.silu(F.group_norm(x, 32, gamma, beta, 1e-5))), w, b, padding=1) + pool(x)
+    xd = hc.to_ndhwc(x).cuda()
+    A, B = _gn_affine(hc, [x], gamma, beta)
+    out, stats, _ = hc.conv3d([xd], w.cuda(), b.cuda(), (12, 4, 4), in_mode=H.IN_POOL, aff=(A, B),
                               act=H.ACT_SILU, res=xd, res_mode=H.RES_POOL)
     assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
     check_stats(stats, ref)

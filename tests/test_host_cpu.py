@@ -42,13 +42,21 @@ def test_library_exports_every_declared_symbol():
     lib.ddpm3d_abi_version.restype = ctypes.c_int
     assert lib.ddpm3d_abi_version() == _hip.ABI_VERSION
     # pure host-side helpers are callable without a GPU
-    lib.ddpm3d_packed_weight_elems.restype = ctypes.c_size_t
-    assert lib.ddpm3d_packed_weight_elems(128, 128, 3) == 27 * 128 * 128
-    assert lib.ddpm3d_packed_weight_elems(2, 128, 3) == 27 * 128 * 32      # Cout padded to 32
-    assert lib.ddpm3d_packed_weight_elems(128, 2, 3) == 27 * 16 * 128      # Cin padded to 16
-    assert lib.ddpm3d_packed_weight_elems(8, 8, 2) == 0
-    assert lib.ddpm3d_conv_stats_rows(64, 64, 64, 128, 3) == 32 * 8 * 8
-    assert lib.ddpm3d_conv_stats_rows(64, 4, 4, 512, 3) == 8
+    lib.ddpm3d_packed_weight_bytes.restype = ctypes.c_size_t
+    assert lib.ddpm3d_packed_weight_bytes(128, 128, 3, 0) == 27 * 128 * 128 * 4
+    assert lib.ddpm3d_packed_weight_bytes(2, 128, 3, 0) == 27 * 128 * 32 * 4      # Cout padded to 32
+    assert lib.ddpm3d_packed_weight_bytes(128, 2, 3, 0) == 27 * 16 * 128 * 4      # Cin padded to 16
+    # split-f16 image: hi+lo f16 = the same bytes, plus one fp32 output scale per padded cout
+    assert lib.ddpm3d_packed_weight_bytes(128, 128, 3, 1) == 27 * 128 * 128 * 4 + 128 * 4
+    assert lib.ddpm3d_packed_weight_bytes(8, 8, 2, 0) == 0 and lib.ddpm3d_packed_weight_bytes(8, 8, 3, 7) == 0
+    lib.ddpm3d_conv_workspace_bytes.restype = ctypes.c_size_t
+    # 64^3 level: 2048 voxel tiles fill the chip, no split, one row per 128-voxel tile
+    assert lib.ddpm3d_conv_stats_rows(1, 64, 64, 64, 128, 128, 3) == 32 * 8 * 8
+    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 64, 64, 128, 128, 3) == 0
+    # 64x4x4 level: 8 voxel tiles -> split over Cin, rows of 16 voxels from the reduce kernel
+    assert lib.ddpm3d_conv_stats_rows(1, 64, 4, 4, 512, 512, 3) == 64
+    ws = lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 512, 512, 3)
+    assert ws > 0 and ws % (1024 * 512 * 4) == 0
 
 
 def test_conv_desc_struct_layout_matches_header():
@@ -56,7 +64,8 @@ def test_conv_desc_struct_layout_matches_header():
     f = {n: getattr(_hip.ConvDesc, n).offset for n, _ in _hip.ConvDesc._fields_}
     assert f["src0"] == 32 and f["C0"] == 48 and f["aff_a"] == 56 and f["act"] == 72
     assert f["w_packed"] == 80 and f["bias_stride_n"] == 96 and f["res"] == 104 and f["out"] == 112
-    assert f["out_layout"] == 120 and f["stats"] == 128 and ctypes.sizeof(_hip.ConvDesc) == 136
+    assert f["out_layout"] == 120 and f["stats"] == 128 and f["workspace"] == 136
+    assert f["workspace_bytes"] == 144 and ctypes.sizeof(_hip.ConvDesc) == 152
 
 
 def test_sr_defaults_and_flag_parsing():
