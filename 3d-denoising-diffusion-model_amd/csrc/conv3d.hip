@@ -32,6 +32,16 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
+// smallest x >= v with x % 16 == res
+constexpr int pad_to_residue(int v, int res) { return v + ((res - v % 16) + 16) % 16; }
+
+// LDS strides (in 16-byte slots) of the halo image; see the bank-conflict note in the kernel.
+template <int TX, int HX, int HY>
+struct LdsGeom {
+    static constexpr int RY = pad_to_residue(HX * 5, TX == 8 ? 8 : 4);
+    static constexpr int RZ = TX == 8 ? HY * RY : pad_to_residue(HY * RY, 0);
+};
+
 template <int PREC, int KS, int WN, int TXL, int TYL>
 __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
     constexpr int CK = DDPM3D_CONV_CK;
@@ -42,11 +52,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
     constexpr int PAD = KS / 2;
     constexpr int HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = TZ + 2 * PAD;
     constexpr int HV = HX * HY * HZ;
-    // LDS row = one halo voxel = 80 bytes in both modes:
-    //   PREC 0: 16 floats + 4 pad;  PREC 1: 16 f16 hi | 16 f16 lo | 8 f16 pad
-    // (5 x 16-byte slots per row: consecutive rows rotate over the 16 slots of the
-    //  ds_read_b128 bank row, so the fragment reads are conflict-light)
-    constexpr int RSB = 80;
+    // LDS image of the halo tile.  One voxel = 80 bytes = 5 slots of 16 B in both modes:
+    //   PREC 0: 16 floats + 4 pad;  PREC 1: 16 f16 hi | 16 f16 lo | 8 f16 pad.
+    // A ds_read_b128 is served in four fixed 16-lane groups, one LDS cycle each when the
+    // 16 lanes hit 16 different slots of the 256-B bank row.  A group's lanes are four
+    // half-rows of 4 consecutive x, so its slots are {0,5,10,15} + offset per half-row and
+    // the four offsets must be {0,4,8,12} in some order: that holds when the x-row stride
+    // is == 8 (8x8 tiles) or == 4 with a z-plane stride == 0 (4x4 tiles), mod 16 slots.
+    // The halo rows / planes are padded to those residues (measured before the padding:
+    // 2/3 of all LDS cycles were bank-conflict cycles, 3-way on every fragment read).
+    constexpr int VS = 5;                                       // slots per voxel
+    constexpr int RY = LdsGeom<TX, HX, HY>::RY;                  // slots per x-row
+    constexpr int RZ = LdsGeom<TX, HX, HY>::RZ;                  // slots per z-plane
     constexpr int QPV = CK / 4;
     constexpr int NT = KS * KS * KS;
 
@@ -71,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
     for (int t = 0; t < MT; ++t) {
         const int m = (wm * MT + t) * 32 + (lane & 31);
         const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
-        arow[t] = ((tz * HY + ty) * HX + tx) * RSB + half * 16;
+        arow[t] = (tz * RZ + ty * RY + tx * VS + half) * 16;
     }
 
     const int cout = blockIdx.y * (32 * WN) + wn * 32 + (lane & 31);
@@ -98,6 +115,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         __syncthreads();  // everyone done reading the previous chunk's tile
         // ------------------------------------------------ stage the halo tile
+#ifdef DDPM3D_ABL_NO_RESTAGE  // (timing experiments only: stage the first chunk, then reuse it)
+        if (chunk == chunk_begin)
+#endif
         {
             const int q = tid % QPV;  // fixed per thread: 256 % QPV == 0
             const HaloSrc hs = halo_src<CK>(p, n, chunk, q);
@@ -109,8 +129,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
                 const int hx = rem - hy * HX;
                 const f32x4 v = halo_fetch<PREC == 1>(p, hs, n, z0 - PAD + hz, y0 - PAD + hy, x0 - PAD + hx, q,
                                                       chunk == 0);
+                unsigned char* vrow = lds + (hz * RZ + hy * RY + hx * VS) * 16;
                 if constexpr (PREC == 0) {
-                    *reinterpret_cast<f32x4*>(lds + hv * RSB + q * 16) = v;
+                    *reinterpret_cast<f32x4*>(vrow + q * 16) = v;
                 } else {
                     h4 hi, lo;
 #pragma unroll
@@ -120,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
                         hi[i] = (_Float16)s;
                         lo[i] = (_Float16)(s - (float)hi[i]);
                     }
-                    *reinterpret_cast<h4*>(lds + hv * RSB + q * 8) = hi;
-                    *reinterpret_cast<h4*>(lds + hv * RSB + 32 + q * 8) = lo;
+                    *reinterpret_cast<h4*>(vrow + q * 8) = hi;
+                    *reinterpret_cast<h4*>(vrow + 32 + q * 8) = lo;
                 }
             }
         }
@@ -135,12 +156,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
         bcur[1] = wchunk[wpart];
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
+#ifndef DDPM3D_ABL_NO_BSTREAM  // (timing experiments only: reuse tap 0's weights)
             if (tap + 1 < NT) {
                 bnxt[0] = wchunk[(size_t)(tap + 1) * wtap_stride];
                 bnxt[1] = wchunk[(size_t)(tap + 1) * wtap_stride + wpart];
             }
+#else
+            bnxt[0] = bcur[0];
+            bnxt[1] = bcur[1];
+#endif
             const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
-            const int tapoff = ((dz * HY + dy) * HX + dx) * RSB;
+            const int tapoff = (dz * RZ + dy * RY + dx * VS) * 16;
             if constexpr (PREC == 0) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -285,8 +311,8 @@ template <int PREC, int KS, int WN, int TXL, int TYL>
 static hipError_t launch_cfg(const ConvK& k, int grid_x, int grid_y, hipStream_t st) {
     constexpr int TX = 1 << TXL, TY = 1 << TYL, TZ = 128 / (TX * TY);
     constexpr int PAD = KS / 2;
-    constexpr int HV = (TX + 2 * PAD) * (TY + 2 * PAD) * (TZ + 2 * PAD);
-    constexpr size_t lds_bytes = (size_t)HV * 80;
+    constexpr int HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = TZ + 2 * PAD;
+    constexpr size_t lds_bytes = (size_t)HZ * LdsGeom<TX, HX, HY>::RZ * 16;
     hipLaunchKernelGGL((conv3d_kernel<PREC, KS, WN, TXL, TYL>), dim3(grid_x, grid_y, k.ksplit), dim3(256),
                        lds_bytes, st, k);
     return hipGetLastError();

@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libddpm3d.so"))
+# DDPM3D_LIB: developer override to A/B an experimental build of the same ABI
+LIB_PATH = os.environ.get("DDPM3D_LIB") or os.path.normpath(os.path.join(_HERE, "..", "csrc", "libddpm3d.so"))
 
 IN_SAME, IN_POOL, IN_UP, IN_PLANAR2 = 0, 1, 2, 3
 RES_NONE, RES_SAME, RES_POOL, RES_UP = 0, 1, 2, 3

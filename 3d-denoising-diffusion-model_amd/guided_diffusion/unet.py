@@ -222,9 +222,10 @@ class UNetModel_noatt(nn.Module):
                                  _zero(nn.Conv3d(t.input_ch, out_channels, 3, padding=1)))
         self._engine = None
         self._engine_key = None
-        # arithmetic of the 3x3x3 convolutions' products: "f32" (exact fp32 MFMA) or
-        # "f16x3" (fp32 emulated by three f16 MFMAs; fp32-equivalent accuracy)
-        self.conv_precision = os.environ.get("DDPM3D_PRECISION", "f32")
+        # arithmetic of the 3x3x3 convolutions' products: "f16x3" (default: each fp32
+        # product = three f16 MFMAs on hi/lo-split operands; error vs fp64 within 2x of
+        # the exact path, tests/test_gpu_ops.py) or "f32" (exact fp32 MFMA, 2.4x slower)
+        self.conv_precision = os.environ.get("DDPM3D_PRECISION", "f16x3")
 
     # ---- precision switches (unet.py:999-1013) -------------------------------
     def convert_to_fp16(self):

@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--arch", choices=["published", "tiny"], default="published")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for cpu_baseline")
-    ap.add_argument("--precision", choices=["f32", "f16x3"], default=os.environ.get("DDPM3D_PRECISION", "f32"),
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default=os.environ.get("DDPM3D_PRECISION", "f16x3"),
                     help="arithmetic of the 3x3x3 conv products (both keep fp32 data and accumulators)")
     args = ap.parse_args()
 
@@ -229,7 +229,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            # fp32 tensors and accumulators in both modes; f16x3 = every fp32 product of the 3x3x3
+            # convs formed as three f16 MFMAs on hi/lo-split operands (fp32-grade error, see tests)
+            "dtype": "f32" if args.precision == "f32" else "f32 (conv products: 3x f16-split MFMA, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "%dx1x%d^3 volume(s) per GPU, %d DDPM steps, %s architecture "
                                    "(SuperResModel_noatt, %d base ch, mult (1,1,2,3,4), %d res blocks, "
