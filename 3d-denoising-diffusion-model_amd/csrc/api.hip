@@ -109,6 +109,17 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     k.ksplit = c.S;
     k.chunks_per_split = (k.CinPad / DDPM3D_CONV_CK + c.S - 1) / c.S;
     k.partial = (float*)d->workspace;
+    {
+        // extents for the kernel's buffer descriptors (32-bit offsets)
+        const long long Hs = d->in_mode == DDPM3D_IN_POOL ? 2LL * d->H : (d->in_mode == DDPM3D_IN_UP ? d->H / 2 : d->H);
+        const long long Ws = d->in_mode == DDPM3D_IN_POOL ? 2LL * d->W : (d->in_mode == DDPM3D_IN_UP ? d->W / 2 : d->W);
+        const long long vox = (long long)d->N * d->D * Hs * Ws;
+        const long long b0 = vox * d->C0 * 4, b1 = vox * d->C1 * 4;
+        const size_t wb = ddpm3d_packed_bytes(d->Cout, d->Cin, d->ksize, d->precision);
+        if (b0 >= 0xFFFFFFF0LL || b1 >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0ULL)
+            return fail(DDPM3D_EINVAL, "conv3d: a source tensor or the weights exceed 4 GiB; split the batch");
+        k.src0_bytes = (unsigned)b0; k.src1_bytes = (unsigned)b1; k.w_bytes = (unsigned)wb;
+    }
     if (c.PREC == DDPM3D_PREC_F16X3)  // output scales sit behind the f16 image
         k.wscale = (const float*)((const char*)d->w_packed +
                                   ddpm3d_packed_bytes(d->Cout, d->Cin, d->ksize, 0));

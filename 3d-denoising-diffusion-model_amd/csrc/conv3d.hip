@@ -42,13 +42,15 @@ struct LdsGeom {
     static constexpr int RZ = TX == 8 ? HY * RY : pad_to_residue(HY * RY, 0);
 };
 
-template <int PREC, int KS, int WN, int TXL, int TYL>
-__global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
+// PIPE = 1: IN_SAME / IN_UP inputs, staging software-pipelined; PIPE = 0: IN_POOL / IN_PLANAR2.
+template <int PREC, int PIPE, int KS, int WN, int MT, int TXL, int TYL>
+__global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_kernel(const ConvK p) {
     constexpr int CK = DDPM3D_CONV_CK;
     constexpr int WM = 4 / WN;
-    constexpr int MT = 4 / WM;  // 32-row accumulators per wave; tile is always 128 voxels
+    // MT = 32-row accumulators per wave; workgroup tile = WM * MT * 32 voxels
+    // (128, or 256 on the full-resolution level: half the weight traffic and barriers per MFMA)
     constexpr int TX = 1 << TXL, TY = 1 << TYL;
-    constexpr int TZ = 128 / (TX * TY);
+    constexpr int TZ = WM * MT * 32 / (TX * TY);
     constexpr int PAD = KS / 2;
     constexpr int HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = TZ + 2 * PAD;
     constexpr int HV = HX * HY * HZ;
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
     constexpr int RZ = LdsGeom<TX, HX, HY>::RZ;                  // slots per z-plane
     constexpr int QPV = CK / 4;
     constexpr int NT = KS * KS * KS;
+    constexpr int NL = (HV * QPV + 255) / 256;                  // staging items per thread
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -97,10 +100,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
     // Weight stream in 16-byte units.
     //   PREC 0: [tap][ci/8][CoutPad][8 f32]            -> 2 units per (8-ci block, cout)
     //   PREC 1: [tap][ci/16][hi|lo][CoutPad][16 f16]   -> 2 units per (16-ci block, part, cout)
-    const uint4* wbase = reinterpret_cast<const uint4*>(p.w) + ((size_t)cout_ld * 2 + half);
-    const size_t wpart = (size_t)p.CoutPad * 2;                       // PREC0: next 8-ci block; PREC1: hi -> lo
-    const size_t wchunk_stride = 2 * wpart;                           // one 16-ci chunk
-    const size_t wtap_stride = (size_t)(p.CinPad / CK) * wchunk_stride;
+    // Addressed as buffer loads: uniform descriptor + ONE per-lane byte offset + a scalar
+    // (chunk, tap, part) byte offset, so nothing per-tap lives in VGPRs.
+    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.w_bytes);
+    const unsigned wlane = ((unsigned)cout_ld * 2 + half) * 16;
+    const unsigned wpart = (unsigned)p.CoutPad * 32;                  // PREC0: next 8-ci block; PREC1: hi -> lo
+    const unsigned wchunk_stride = 2 * wpart;                         // one 16-ci chunk
+    const unsigned wtap_stride = (unsigned)(p.CinPad / CK) * wchunk_stride;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -112,6 +118,42 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
     // split-K: blockIdx.z owns a contiguous range of the Cin chunks
     const int chunk_begin = blockIdx.z * p.chunks_per_split;
     const int chunk_end = min(nchunks, chunk_begin + p.chunks_per_split);
+
+    // Software pipeline of the staging (IN_SAME / IN_UP, one 16-byte load per item): the
+    // raw loads of chunk c+1 are issued near the end of chunk c's tap loop and finished
+    // (affine + activation + LDS store) after the barrier.  vmcnt retires in issue order,
+    // so they are issued only AFTER the chunk's last weight loads: a weight wait must never
+    // sit behind the long-latency halo loads.
+    const int q = tid % QPV;  // fixed per thread: 256 % QPV == 0
+    const int up_shift = p.in_mode == DDPM3D_IN_UP ? 1 : 0;
+    const unsigned act_mask = p.act ? 0xFFFFFFFFu : 0u;
+    f32x4 raw[PIPE ? NL : 1];
+    HaloSrc hs = halo_src<CK>(p, n, chunk_begin < chunk_end ? chunk_begin : 0, q);
+    // source voxel of each staging item (-1 = zero padding): launch-invariant, one VGPR each
+    int vox[PIPE ? NL : 1];
+#pragma unroll
+    for (int i = 0; i < (PIPE ? NL : 0); ++i) {
+        const int idx = tid + i * 256;
+        const int hv = idx / QPV;
+        const int hz = hv / (HY * HX);
+        const int rem = hv - hz * (HY * HX);
+        const int hy = rem / HX;
+        const int hx = rem - hy * HX;
+        vox[i] = idx < HV * QPV ? halo_vox(p, n, z0 - PAD + hz, y0 - PAD + hy, x0 - PAD + hx, hs.Hs, hs.Ws, up_shift)
+                                : -1;
+    }
+    auto issue_raw = [&](const HaloSrc& h) {
+        const __amdgpu_buffer_rsrc_t srsrc = make_rsrc(h.src, h.src_bytes);  // uniform: src0 or src1
+        const unsigned row_bytes = (unsigned)h.Cs * 4, soff = (unsigned)h.cb * 4;
+#pragma unroll
+        for (int i = 0; i < (PIPE ? NL : 0); ++i) {
+            // out-of-range offset -> the buffer load returns 0 = the conv's zero padding
+            const unsigned voff = vox[i] < 0 ? DDPM3D_OOB_OFFSET : (unsigned)vox[i] * row_bytes + q * 16;
+            raw[i] = __builtin_bit_cast(f32x4, buffer_load16(srsrc, voff, soff));
+        }
+    };
+    if (PIPE && chunk_begin < chunk_end) issue_raw(hs);
+
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         __syncthreads();  // everyone done reading the previous chunk's tile
         // ------------------------------------------------ stage the halo tile
@@ -119,54 +161,87 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
         if (chunk == chunk_begin)
 #endif
         {
-            const int q = tid % QPV;  // fixed per thread: 256 % QPV == 0
-            const HaloSrc hs = halo_src<CK>(p, n, chunk, q);
-            for (int idx = tid; idx < HV * QPV; idx += 256) {
-                const int hv = idx / QPV;
-                const int hz = hv / (HY * HX);
-                const int rem = hv - hz * (HY * HX);
-                const int hy = rem / HX;
-                const int hx = rem - hy * HX;
-                const f32x4 v = halo_fetch<PREC == 1>(p, hs, n, z0 - PAD + hz, y0 - PAD + hy, x0 - PAD + hx, q,
-                                                      chunk == 0);
+            auto store_item = [&](int hz, int hy, int hx, const f32x4 v) {
                 unsigned char* vrow = lds + (hz * RZ + hy * RY + hx * VS) * 16;
                 if constexpr (PREC == 0) {
                     *reinterpret_cast<f32x4*>(vrow + q * 16) = v;
                 } else {
                     h4 hi, lo;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int c = 0; c < 4; ++c) {
                         // x8: keeps lo = x - hi a normal f16 down to |x| ~ 2^-6; clamp keeps hi finite
-                        const float s = fminf(fmaxf(v[i] * DDPM3D_X3_ACT_SCALE, -60000.0f), 60000.0f);
-                        hi[i] = (_Float16)s;
-                        lo[i] = (_Float16)(s - (float)hi[i]);
+                        const float s = fminf(fmaxf(v[c] * DDPM3D_X3_ACT_SCALE, -60000.0f), 60000.0f);
+                        hi[c] = (_Float16)s;
+                        lo[c] = (_Float16)(s - (float)hi[c]);
                     }
                     *reinterpret_cast<h4*>(vrow + q * 8) = hi;
                     *reinterpret_cast<h4*>(vrow + 32 + q * 8) = lo;
                 }
+            };
+            if constexpr (PIPE) {
+                // finish the prefetched items (no loads here: unrolled for static raw[] indexing)
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    const int idx = tid + i * 256;
+                    if (idx < HV * QPV) {
+                        const int hv = idx / QPV;
+                        const int hz = hv / (HY * HX);
+                        const int rem = hv - hz * (HY * HX);
+                        const int hy = rem / HX;
+                        const int hx = rem - hy * HX;
+                        const bool inb = halo_inb(p, z0 - PAD + hz, y0 - PAD + hy, x0 - PAD + hx);
+                        store_item(hz, hy, hx, halo_finish<PREC == 1>(hs, raw[i], inb, act_mask));
+                    }
+                }
+            } else {
+                // pool / planar inputs: fetch + transform in place (rolled loop: an item is up to 4 loads)
+#pragma unroll 1
+                for (int idx = tid; idx < HV * QPV; idx += 256) {
+                    const int hv = idx / QPV;
+                    const int hz = hv / (HY * HX);
+                    const int rem = hv - hz * (HY * HX);
+                    const int hy = rem / HX;
+                    const int hx = rem - hy * HX;
+                    store_item(hz, hy, hx, halo_fetch<PREC == 1>(p, hs, n, z0 - PAD + hz, y0 - PAD + hy,
+                                                                 x0 - PAD + hx, q, chunk == 0));
+                }
             }
         }
         __syncthreads();
-        if (!wave_active) continue;
+        const bool more = chunk + 1 < chunk_end;
+        if (more) hs = halo_src<CK>(p, n, chunk + 1, q);  // also loads the next chunk's affine quad
+        if (!wave_active) {  // (only with a cout tile beyond CoutPad) still owns staging items
+            if (PIPE && more) issue_raw(hs);
+            continue;
+        }
 
         // ------------------------------------------------ taps x k-steps
-        const uint4* wchunk = wbase + (size_t)chunk * wchunk_stride;
-        uint4 bcur[2], bnxt[2];
-        bcur[0] = wchunk[0];
-        bcur[1] = wchunk[wpart];
+        // weight ring of 3 taps (prefetch distance 2), statically indexed by the unrolled tap
+        const unsigned wchunk = (unsigned)chunk * wchunk_stride;  // scalar byte offset of this chunk
+        u32x4 bq[3][2];
+        bq[0][0] = buffer_load16(wrsrc, wlane, wchunk);
+        bq[0][1] = buffer_load16(wrsrc, wlane, wchunk + wpart);
+        if (NT > 1) {
+            bq[1][0] = buffer_load16(wrsrc, wlane, wchunk + wtap_stride);
+            bq[1][1] = buffer_load16(wrsrc, wlane, wchunk + wtap_stride + wpart);
+        }
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
-#ifndef DDPM3D_ABL_NO_BSTREAM  // (timing experiments only: reuse tap 0's weights)
-            if (tap + 1 < NT) {
-                bnxt[0] = wchunk[(size_t)(tap + 1) * wtap_stride];
-                bnxt[1] = wchunk[(size_t)(tap + 1) * wtap_stride + wpart];
+#ifndef DDPM3D_ABL_NO_BSTREAM  // (timing experiments only: reuse the first taps' weights)
+            if (tap + 2 < NT) {
+                bq[(tap + 2) % 3][0] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride);
+                bq[(tap + 2) % 3][1] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride + wpart);
             }
-#else
-            bnxt[0] = bcur[0];
-            bnxt[1] = bcur[1];
 #endif
+            // all of this chunk's weight loads are in flight: now the next chunk's halo loads
+            if (PIPE && tap == (NT >= 3 ? NT - 3 : 0) && more) issue_raw(hs);
             const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
             const int tapoff = (dz * RZ + dy * RY + dx * VS) * 16;
+#ifdef DDPM3D_ABL_NO_BSTREAM
+            const u32x4 b0 = bq[tap % 2][0], b1 = bq[tap % 2][1];
+#else
+            const u32x4 b0 = bq[tap % 3][0], b1 = bq[tap % 3][1];
+#endif
             if constexpr (PREC == 0) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -174,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
                         a[t] = *reinterpret_cast<const f32x4*>(lds + arow[t] + tapoff + kk * 32);
-                    const f32x4 b = __builtin_bit_cast(f32x4, bcur[kk]);
+                    const f32x4 b = __builtin_bit_cast(f32x4, kk == 0 ? b0 : b1);
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -182,8 +257,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
                             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], b[s], acc[t], 0, 0, 0);
                 }
             } else {
-                const h8 bhi = __builtin_bit_cast(h8, bcur[0]);
-                const h8 blo = __builtin_bit_cast(h8, bcur[1]);
+                const h8 bhi = __builtin_bit_cast(h8, b0);
+                const h8 blo = __builtin_bit_cast(h8, b1);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     const h8 ahi = *reinterpret_cast<const h8*>(lds + arow[t] + tapoff);
@@ -192,10 +267,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_kernel(const ConvK p) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[t], 0, 0, 0);
                 }
-            }
-            if (tap + 1 < NT) {
-                bcur[0] = bnxt[0];
-                bcur[1] = bnxt[1];
             }
         }
     }
@@ -301,19 +372,84 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) 
     }
 }
 
+// Vectorised form for Cout % 4 == 0 and NDHWC output (every split conv of the network):
+// thread = (voxel lane vl = tid/64, channel quad cq = tid%64); each thread sums the S slabs
+// for 4 voxels x 4 channels with 16-byte loads (4 independent chains per pass instead of one
+// 16-voxel serial chain), then the 4 voxel lanes are folded through LDS for the statistics row.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK p) {
+    const size_t DHW = (size_t)p.D * p.H * p.W;
+    const int rows = p.stats_rows;
+    const int n = blockIdx.x / rows, r = blockIdx.x % rows;
+    const size_t v0 = (size_t)r * DDPM3D_REDUCE_VOX;
+    const size_t slab_stride = (size_t)p.N * DHW * p.Cout;
+    const int quads = p.Cout / 4;
+    const int cq = threadIdx.x & 63, vl = threadIdx.x >> 6;
+    __shared__ float red[2][4][64 * 4];
+    for (int q0 = 0; q0 < quads; q0 += 64) {
+        const int q = q0 + cq;
+        const bool qok = q < quads;
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        if (qok) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + (size_t)n * p.bias_stride_n + q * 4);
+#pragma unroll
+            for (int i = 0; i < DDPM3D_REDUCE_VOX / 4; ++i) {
+                const size_t v = v0 + vl + 4 * i;
+                if (v < DHW) {
+                    const size_t e = ((size_t)n * DHW + v) * p.Cout + q * 4;
+                    f32x4 val = *reinterpret_cast<const f32x4*>(p.partial + e);
+                    for (int s = 1; s < p.ksplit; ++s)
+                        val += *reinterpret_cast<const f32x4*>(p.partial + e + s * slab_stride);
+                    val += bias;
+                    if (p.res_mode != DDPM3D_RES_NONE) {
+                        const int x = (int)(v % p.W), y = (int)((v / p.W) % p.H), z = (int)(v / ((size_t)p.W * p.H));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) val[c] += ddpm3d_residual(p, n, z, y, x, q * 4 + c);
+                    }
+                    *reinterpret_cast<f32x4*>(p.out + e) = val;
+                    s1 += val;
+                    s2 += val * val;
+                }
+            }
+        }
+        if (p.stats != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                red[0][vl][cq * 4 + c] = s1[c];
+                red[1][vl][cq * 4 + c] = s2[c];
+            }
+            __syncthreads();
+            if (vl == 0 && qok) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float a = (red[0][0][cq * 4 + c] + red[0][1][cq * 4 + c]) +
+                                    (red[0][2][cq * 4 + c] + red[0][3][cq * 4 + c]);
+                    const float b = (red[1][0][cq * 4 + c] + red[1][1][cq * 4 + c]) +
+                                    (red[1][2][cq * 4 + c] + red[1][3][cq * 4 + c]);
+                    *reinterpret_cast<float2*>(p.stats + (((size_t)n * rows + r) * p.Cout + q * 4 + c) * 2) =
+                        make_float2(a, b);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st) {
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(k.N * k.stats_rows), dim3(256), 0, st, k);
+    if (k.Cout % 4 == 0 && k.out_layout == DDPM3D_OUT_NDHWC)
+        hipLaunchKernelGGL(conv_splitk_reduce_v4_kernel, dim3(k.N * k.stats_rows), dim3(256), 0, st, k);
+    else
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(k.N * k.stats_rows), dim3(256), 0, st, k);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- dispatch
-template <int PREC, int KS, int WN, int TXL, int TYL>
+template <int PREC, int PIPE, int KS, int WN, int MT, int TXL, int TYL>
 static hipError_t launch_cfg(const ConvK& k, int grid_x, int grid_y, hipStream_t st) {
-    constexpr int TX = 1 << TXL, TY = 1 << TYL, TZ = 128 / (TX * TY);
+    constexpr int TX = 1 << TXL, TY = 1 << TYL, TZ = (4 / WN) * MT * 32 / (TX * TY);
     constexpr int PAD = KS / 2;
     constexpr int HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = TZ + 2 * PAD;
     constexpr size_t lds_bytes = (size_t)HZ * LdsGeom<TX, HX, HY>::RZ * 16;
-    hipLaunchKernelGGL((conv3d_kernel<PREC, KS, WN, TXL, TYL>), dim3(grid_x, grid_y, k.ksplit), dim3(256),
+    hipLaunchKernelGGL((conv3d_kernel<PREC, PIPE, KS, WN, MT, TXL, TYL>), dim3(grid_x, grid_y, k.ksplit), dim3(256),
                        lds_bytes, st, k);
     return hipGetLastError();
 }
@@ -321,17 +457,23 @@ static hipError_t launch_cfg(const ConvK& k, int grid_x, int grid_y, hipStream_t
 hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) {
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     const int gy = (k.CoutPad + 32 * c.WN - 1) / (32 * c.WN);
-#define CASE(P_, KS_, WN_, TXL_, TYL_)                                                   \
-    if (c.PREC == P_ && c.KS == KS_ && c.WN == WN_ && c.TXL == TXL_ && c.TYL == TYL_)   \
-        return launch_cfg<P_, KS_, WN_, TXL_, TYL_>(k, gx, gy, st);
-    CASE(0, 3, 4, 3, 3) CASE(0, 3, 2, 3, 3) CASE(0, 3, 1, 3, 3)
-    CASE(0, 3, 4, 2, 2) CASE(0, 3, 2, 2, 2) CASE(0, 3, 1, 2, 2)
-    CASE(0, 1, 4, 3, 3) CASE(0, 1, 2, 3, 3) CASE(0, 1, 1, 3, 3)
-    CASE(0, 1, 4, 2, 2) CASE(0, 1, 2, 2, 2) CASE(0, 1, 1, 2, 2)
-    CASE(1, 3, 4, 3, 3) CASE(1, 3, 2, 3, 3) CASE(1, 3, 1, 3, 3)
-    CASE(1, 3, 4, 2, 2) CASE(1, 3, 2, 2, 2) CASE(1, 3, 1, 2, 2)
-    CASE(1, 1, 4, 3, 3) CASE(1, 1, 2, 3, 3) CASE(1, 1, 1, 3, 3)
-    CASE(1, 1, 4, 2, 2) CASE(1, 1, 2, 2, 2) CASE(1, 1, 1, 2, 2)
+    const int pipe = (k.in_mode == DDPM3D_IN_SAME || k.in_mode == DDPM3D_IN_UP) ? 1 : 0;
+#define CASE(P_, PI_, KS_, WN_, MT_, TXL_, TYL_)                                                      \
+    if (c.PREC == P_ && pipe == PI_ && c.KS == KS_ && c.WN == WN_ && c.MT == MT_ && c.TXL == TXL_ &&  \
+        c.TYL == TYL_)                                                                                \
+        return launch_cfg<P_, PI_, KS_, WN_, MT_, TXL_, TYL_>(k, gx, gy, st);
+#define CASES(P_, PI_)                                                                          \
+    CASE(P_, PI_, 3, 4, 8, 3, 3)                                                                \
+    CASE(P_, PI_, 3, 4, 4, 3, 3) CASE(P_, PI_, 3, 2, 2, 3, 3) CASE(P_, PI_, 3, 1, 1, 3, 3)      \
+    CASE(P_, PI_, 3, 4, 4, 2, 2) CASE(P_, PI_, 3, 2, 2, 2, 2) CASE(P_, PI_, 3, 1, 1, 2, 2)      \
+    CASE(P_, PI_, 1, 4, 4, 3, 3) CASE(P_, PI_, 1, 2, 2, 3, 3) CASE(P_, PI_, 1, 1, 1, 3, 3)      \
+    CASE(P_, PI_, 1, 4, 4, 2, 2) CASE(P_, PI_, 1, 2, 2, 2, 2) CASE(P_, PI_, 1, 1, 1, 2, 2)
+#ifdef DDPM3D_ONLY_ONE  // (compile-time experiments: a single instantiation)
+    CASE(1, 1, 3, 4, 4, 3, 3)
+#else
+    CASES(0, 1) CASES(1, 1) CASES(0, 0) CASES(1, 0)
+#endif
+#undef CASES
 #undef CASE
     return hipErrorInvalidValue;
 }

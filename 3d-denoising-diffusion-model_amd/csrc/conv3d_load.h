@@ -31,6 +31,7 @@ __device__ __forceinline__ f32x4 affine_act(f32x4 v, f32x4 a, f32x4 b) {
 
 struct HaloSrc {
     const float* src;  // source tensor of this chunk (after the concat split)
+    unsigned src_bytes;  // its extent (buffer descriptor num_records)
     int Cs;            // its channel count
     int cb;            // first channel of the chunk inside it
     int Hs, Ws;        // its H, W
@@ -44,6 +45,7 @@ __device__ __forceinline__ HaloSrc halo_src(const ConvK& p, int n, int chunk, in
     const int c0 = chunk * CK;
     const bool from0 = c0 < p.C0;
     h.src = from0 ? p.src0 : p.src1;
+    h.src_bytes = from0 ? p.src0_bytes : p.src1_bytes;
     h.Cs = from0 ? p.C0 : p.C1;
     h.cb = from0 ? c0 : c0 - p.C0;
     h.Hs = p.in_mode == DDPM3D_IN_POOL ? 2 * p.H : (p.in_mode == DDPM3D_IN_UP ? p.H / 2 : p.H);
@@ -98,6 +100,51 @@ __device__ __forceinline__ f32x4 halo_fetch(const ConvK& p, const HaloSrc& h, in
         }
     }
     return v;
+}
+
+// Two-phase form used by the software pipeline (IN_SAME / IN_UP only, where an item is
+// ONE 16-byte load): `halo_raw` issues the load for the next chunk while the current
+// chunk's MFMAs run; `halo_finish` applies affine + activation when the data is needed.
+__device__ __forceinline__ bool halo_inb(const ConvK& p, int z, int y, int x) {
+    return (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+}
+
+// Buffer addressing (SRD + 32-bit per-lane offset + SCALAR offset): with flat 64-bit
+// pointers LLVM hoists one VGPR address pair per unrolled tap / staging item out of the chunk
+// loop (54 pairs for the weights alone), spills them and then waits vmcnt(0) behind every
+// reload.  A uniform descriptor leaves nothing per-tap to hoist, and an offset beyond
+// num_records reads as 0, which is exactly the conv's zero padding (no branch).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define DDPM3D_OOB_OFFSET 0xFFFFFFF0u
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buffer_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+
+// Voxel index (in the SOURCE tensor's D x Hs x Ws grid) of a halo item, or -1 outside the
+// conv's zero padding.  Launch-invariant per item: computed once, kept in one VGPR.
+__device__ __forceinline__ int halo_vox(const ConvK& p, int n, int z, int y, int x, int Hs, int Ws, int up_shift) {
+    if (!halo_inb(p, z, y, x)) return -1;
+    return ((n * p.D + z) * Hs + (y >> up_shift)) * Ws + (x >> up_shift);
+}
+
+// "no affine" is A = 1, B = 0 (exact) and "no activation" is a bit-mask select: a
+// launch-invariant branch here would make LLVM unswitch the whole chunk loop.
+template <bool FAST>
+__device__ __forceinline__ f32x4 halo_finish(const HaloSrc& h, f32x4 raw, bool inb, unsigned act_mask) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float y = fmaf(raw[i], h.ga[i], h.gb[i]);
+        const float s = silu_f<FAST>(y);
+        const unsigned bits = (__builtin_bit_cast(unsigned, s) & act_mask) |
+                              (__builtin_bit_cast(unsigned, y) & ~act_mask);
+        r[i] = inb ? __builtin_bit_cast(float, bits) : 0.0f;  // out-of-bounds voxels stay exact zeros
+    }
+    return r;
 }
 
 // XCD-aware tile order: consecutive tiles (which share halo planes) on one XCD's L2.

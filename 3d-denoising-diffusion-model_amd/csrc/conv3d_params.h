@@ -27,6 +27,7 @@ struct ConvK {
     float* stats;
     float* partial;  // split-K slabs [ksplit][N*D*H*W][Cout], raw accumulators
     const float* wscale;  // PREC 1: per-cout 1 / (activation scale * weight scale)
+    unsigned w_bytes, src0_bytes, src1_bytes;  // extents for the buffer resource descriptors
     int N, D, H, W, Cin, Cout, C0, C1, CinPad, CoutPad;
     int in_mode, act, bias_stride_n, res_mode, out_layout, stats_rows;
     int tilesX, tilesY, tilesZ;
@@ -37,6 +38,7 @@ struct ConvCfg {
     int PREC;      // 0 exact fp32 MFMA, 1 split-f16 (3 MFMA per product)
     int KS;        // 3 or 1
     int WN;        // waves along Cout (4, 2, 1); waves along voxels = 4 / WN
+    int MT;        // 32-voxel accumulators per wave; tile = (4/WN) * MT * 32 voxels (128 or 256)
     int TXL, TYL;  // log2 of the tile extent in W and H; tile depth = 128 >> (TXL+TYL)
     int S;         // split-K factor over the Cin chunks (1 = none)
     int tilesX, tilesY, tilesZ;
@@ -63,7 +65,15 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
     c.KS = ksize;
     c.WN = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
     if (H >= 8 && W >= 8) { c.TXL = 3; c.TYL = 3; } else { c.TXL = 2; c.TYL = 2; }
-    const int TX = 1 << c.TXL, TY = 1 << c.TYL, TZ = 128 / (TX * TY);
+    c.MT = c.WN;  // 128-voxel tile
+    {
+        // A 256-voxel tile (8 accumulators per wave) halves the weight stream and the barriers
+        // per MFMA, but as compiled today (2 waves/SIMD, 254 VGPRs) it measured 2.2x SLOWER than
+        // the 128-voxel tile on the 64^3 level (159 vs 353 TFLOP/s): opt-in for experiments only.
+        const char* force = getenv("DDPM3D_MT8");
+        if (c.WN == 4 && c.TXL == 3 && ksize == 3 && force && atoi(force) != 0) c.MT = 8;
+    }
+    const int TX = 1 << c.TXL, TY = 1 << c.TYL, TZ = (4 / c.WN) * c.MT * 32 / (TX * TY);
     c.tilesX = (W + TX - 1) / TX;
     c.tilesY = (H + TY - 1) / TY;
     c.tilesZ = (D + TZ - 1) / TZ;

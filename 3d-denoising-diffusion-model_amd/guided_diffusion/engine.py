@@ -58,9 +58,9 @@ class UNetEngine:
     """Executes one model on one device.  `layers` is unet.py's topology."""
 
     def __init__(self, topo, params, model_channels, film, device, precision="f32"):
-        """precision: "f32" = exact fp32 MFMA everywhere; "f16x3" = the 3x3x3 convs
-        evaluate each fp32 product as three f16 MFMAs (fp32-equivalent accuracy, see
-        include/ddpm3d.h); 1x1x1 convs (HBM-bound) stay on the exact path."""
+        """precision: "f32" = exact fp32 MFMA everywhere; "f16x3" = every conv evaluates
+        each fp32 product as three f16 MFMAs (fp32-equivalent accuracy, see
+        include/ddpm3d.h)."""
         if precision not in H.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(H.PRECISIONS))
         self.precision = precision
@@ -77,7 +77,7 @@ class UNetEngine:
             if name.endswith(".weight") and t.dim() >= 3:
                 base = name[:-len(".weight")]
                 w = t if t.dim() == 5 else t.reshape(t.shape[0], t.shape[1], 1, 1, 1)
-                prec = H.PRECISIONS[precision] if w.shape[2] == 3 else H.PREC_F32
+                prec = H.PRECISIONS[precision]
                 self.conv[base] = PackedConv(w, params[base + ".bias"], prec, st)
         # fuse every ResBlock's emb_layers Linear into one [total, ted] matrix
         ws, bs, self.film_off = [], [], {}

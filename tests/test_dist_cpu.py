@@ -1,0 +1,71 @@
+"""
+N>1 host logic on CPU: two gloo ranks exercise the partition / padding /
+gather / index-keyed-noise rules that the GPU ranks use over RCCL.
+"""
+
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from guided_diffusion import dist_util
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_denoise(index):
+    """Stands in for one volume's sampler run: depends only on the GLOBAL index."""
+    g = dist_util.volume_generator(index, seed=10, device="cpu")
+    return torch.randn(1, 1, 4, 4, 4, generator=g) + index
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist_util.setup_dist(backend="gloo")
+    assert dist_util.rank() == rank and dist_util.world_size() == world
+    mine = dist_util.partition(n_items)
+    collected = []
+    for idx in mine:                      # every rank runs the same number of rounds
+        sample = _fake_denoise(idx) if idx is not None else torch.zeros(1, 1, 4, 4, 4)
+        collected += dist_util.gather_round(sample, idx)
+    dist_util.barrier()
+    q.put((rank, mine, [(i, t.clone()) for i, t in collected]))
+    dist.destroy_process_group()
+
+
+def test_partition_rule():
+    assert dist_util.partition(5, 0, 2) == [0, 2, 4]
+    assert dist_util.partition(5, 1, 2) == [1, 3, None]          # padded: same number of rounds
+    assert dist_util.partition(18, 3, 8) == [3, 11, None]        # the reference's 18 patches on 8 GPUs
+    assert dist_util.partition(3, 0, 1) == [0, 1, 2]
+    allv = sorted(i for r in range(8) for i in dist_util.partition(18, r, 8) if i is not None)
+    assert allv == list(range(18))
+
+
+def test_two_ranks_gloo_match_single_process():
+    n_items = 5                                    # uneven on purpose
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = {i: _fake_denoise(i) for i in range(n_items)}
+    for rank, mine, collected in res:
+        assert mine == dist_util.partition(n_items, rank, 2)
+        assert [i for i, _ in collected] == list(range(n_items))     # every rank ends with all samples
+        for i, t in collected:
+            assert torch.equal(t, expect[i])                         # same as a 1-rank run

@@ -50,8 +50,10 @@ def test_library_exports_every_declared_symbol():
     assert lib.ddpm3d_packed_weight_bytes(128, 128, 3, 1) == 27 * 128 * 128 * 4 + 128 * 4
     assert lib.ddpm3d_packed_weight_bytes(8, 8, 2, 0) == 0 and lib.ddpm3d_packed_weight_bytes(8, 8, 3, 7) == 0
     lib.ddpm3d_conv_workspace_bytes.restype = ctypes.c_size_t
-    # 64^3 level: 2048 voxel tiles fill the chip, no split, one row per 128-voxel tile
+    # 64^3 level: 2048 tiles of 128 voxels (2x8x8) fill the chip, no split, one row per tile
     assert lib.ddpm3d_conv_stats_rows(1, 64, 64, 64, 128, 128, 3) == 32 * 8 * 8
+    # 64x32x32 level: 128-voxel tiles (2x8x8)
+    assert lib.ddpm3d_conv_stats_rows(1, 64, 32, 32, 128, 128, 3) == 32 * 4 * 4
     assert lib.ddpm3d_conv_workspace_bytes(1, 64, 64, 64, 128, 128, 3) == 0
     # 64x4x4 level: 8 voxel tiles -> split over Cin, rows of 16 voxels from the reduce kernel
     assert lib.ddpm3d_conv_stats_rows(1, 64, 4, 4, 512, 512, 3) == 64
