@@ -28,7 +28,7 @@ extern "C" {
 int ddpm3d_abi_version(void) { return DDPM3D_ABI_VERSION; }
 const char* ddpm3d_last_error(void) { return g_err; }
 
-static bool prec_ok(int p) { return p == DDPM3D_PREC_F32 || p == DDPM3D_PREC_F16X3; }
+static bool prec_ok(int p) { return p == DDPM3D_PREC_F32 || p == DDPM3D_PREC_F16X3 || p == DDPM3D_PREC_F16; }
 
 size_t ddpm3d_packed_weight_bytes(int Cout, int Cin, int ksize, int precision) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || !prec_ok(precision)) return 0;
@@ -120,7 +120,7 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
             return fail(DDPM3D_EINVAL, "conv3d: a source tensor or the weights exceed 4 GiB; split the batch");
         k.src0_bytes = (unsigned)b0; k.src1_bytes = (unsigned)b1; k.w_bytes = (unsigned)wb;
     }
-    if (c.PREC == DDPM3D_PREC_F16X3)  // output scales sit behind the f16 image
+    if (c.PREC != DDPM3D_PREC_F32)  // output scales sit behind the f16 image
         k.wscale = (const float*)((const char*)d->w_packed +
                                   ddpm3d_packed_bytes(d->Cout, d->Cin, d->ksize, 0));
     if (d->stats && d->stats_rows != k.stats_rows)

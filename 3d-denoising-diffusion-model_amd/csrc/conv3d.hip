@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
                         lo[c] = (_Float16)(s - (float)hi[c]);
                     }
                     *reinterpret_cast<h4*>(vrow + q * 8) = hi;
-                    *reinterpret_cast<h4*>(vrow + 32 + q * 8) = lo;
+                    if constexpr (PREC == 1) *reinterpret_cast<h4*>(vrow + 32 + q * 8) = lo;
                 }
             };
             if constexpr (PIPE) {
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
                         const int hy = rem / HX;
                         const int hx = rem - hy * HX;
                         const bool inb = halo_inb(p, z0 - PAD + hz, y0 - PAD + hy, x0 - PAD + hx);
-                        store_item(hz, hy, hx, halo_finish<PREC == 1>(hs, raw[i], inb, act_mask));
+                        store_item(hz, hy, hx, halo_finish<PREC != 0>(hs, raw[i], inb, act_mask));
                     }
                 }
             } else {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
                     const int rem = hv - hz * (HY * HX);
                     const int hy = rem / HX;
                     const int hx = rem - hy * HX;
-                    store_item(hz, hy, hx, halo_fetch<PREC == 1>(p, hs, n, z0 - PAD + hz, y0 - PAD + hy,
+                    store_item(hz, hy, hx, halo_fetch<PREC != 0>(p, hs, n, z0 - PAD + hz, y0 - PAD + hy,
                                                                  x0 - PAD + hx, q, chunk == 0));
                 }
             }
@@ -218,19 +218,20 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
         // ------------------------------------------------ taps x k-steps
         // weight ring of 3 taps (prefetch distance 2), statically indexed by the unrolled tap
         const unsigned wchunk = (unsigned)chunk * wchunk_stride;  // scalar byte offset of this chunk
+        constexpr bool LO = PREC != 2;  // PREC 2 streams only the hi halves
         u32x4 bq[3][2];
         bq[0][0] = buffer_load16(wrsrc, wlane, wchunk);
-        bq[0][1] = buffer_load16(wrsrc, wlane, wchunk + wpart);
+        if (LO) bq[0][1] = buffer_load16(wrsrc, wlane, wchunk + wpart);
         if (NT > 1) {
             bq[1][0] = buffer_load16(wrsrc, wlane, wchunk + wtap_stride);
-            bq[1][1] = buffer_load16(wrsrc, wlane, wchunk + wtap_stride + wpart);
+            if (LO) bq[1][1] = buffer_load16(wrsrc, wlane, wchunk + wtap_stride + wpart);
         }
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
 #ifndef DDPM3D_ABL_NO_BSTREAM  // (timing experiments only: reuse the first taps' weights)
             if (tap + 2 < NT) {
                 bq[(tap + 2) % 3][0] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride);
-                bq[(tap + 2) % 3][1] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride + wpart);
+                if (LO) bq[(tap + 2) % 3][1] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride + wpart);
             }
 #endif
             // all of this chunk's weight loads are in flight: now the next chunk's halo loads
@@ -238,9 +239,9 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
             const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
             const int tapoff = (dz * RZ + dy * RY + dx * VS) * 16;
 #ifdef DDPM3D_ABL_NO_BSTREAM
-            const u32x4 b0 = bq[tap % 2][0], b1 = bq[tap % 2][1];
+            const u32x4 b0 = bq[tap % 2][0], b1 = LO ? bq[tap % 2][1] : b0;
 #else
-            const u32x4 b0 = bq[tap % 3][0], b1 = bq[tap % 3][1];
+            const u32x4 b0 = bq[tap % 3][0], b1 = LO ? bq[tap % 3][1] : b0;
 #endif
             if constexpr (PREC == 0) {
 #pragma unroll
@@ -255,6 +256,14 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
 #pragma unroll
                         for (int t = 0; t < MT; ++t)
                             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], b[s], acc[t], 0, 0, 0);
+                }
+            } else if constexpr (PREC == 2) {
+                // single product on the f16-rounded operands (the reference's --use_fp16 analogue)
+                const h8 bhi = __builtin_bit_cast(h8, b0);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const h8 ahi = *reinterpret_cast<const h8*>(lds + arow[t] + tapoff);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[t], 0, 0, 0);
                 }
             } else {
                 const h8 bhi = __builtin_bit_cast(h8, b0);
@@ -278,7 +287,7 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
     const bool cvalid = cout < p.Cout;
     const size_t DHW = (size_t)p.D * p.H * p.W;
     // PREC 1: undo the operand scaling (exact: a power of two per cout)
-    const float oscale = (PREC == 1 && cvalid) ? p.wscale[cout] : 1.0f;
+    const float oscale = (PREC != 0 && cvalid) ? p.wscale[cout] : 1.0f;
     if (p.ksplit > 1) {
         // split-K: raw partial sums to this split's slab; bias / residual / statistics
         // are applied by the reduce kernel once all splits are in
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
                 const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
                 if (cvalid && z < p.D && y < p.H && x < p.W)
                     slab[(((size_t)z * p.H + y) * p.W + x) * p.Cout + cout] =
-                        PREC == 1 ? acc[t][reg] * oscale : acc[t][reg];
+                        PREC != 0 ? acc[t][reg] * oscale : acc[t][reg];
             }
         }
         return;
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
             const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
             const bool ok = cvalid && z < p.D && y < p.H && x < p.W;
             if (ok) {
-                float val = (PREC == 1 ? acc[t][reg] * oscale : acc[t][reg]) + bias;
+                float val = (PREC != 0 ? acc[t][reg] * oscale : acc[t][reg]) + bias;
                 const size_t vox = ((size_t)z * p.H + y) * p.W + x;
                 if (p.res_mode != DDPM3D_RES_NONE) val += ddpm3d_residual(p, n, z, y, x, cout);
                 if (p.out_layout == DDPM3D_OUT_NDHWC)
@@ -333,6 +342,14 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
         }
     }
 }
+
+// This file is compiled once per arithmetic mode (-DDDPM3D_PREC_ONLY=0|1|2, see the
+// Makefile) so the instantiations build in parallel; the mode-independent parts below
+// (split-K reduction, dispatcher) live in the PREC 0 object only.
+#ifndef DDPM3D_PREC_ONLY
+#error "compile with -DDDPM3D_PREC_ONLY=0, 1 or 2"
+#endif
+#if DDPM3D_PREC_ONLY == 0
 
 // ------------------------------------------------------- split-K reduction
 // out = sum_s slab[s] + bias + residual, plus the GroupNorm partial sums the
@@ -442,6 +459,20 @@ hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st) {
     return hipGetLastError();
 }
 
+hipError_t ddpm3d_launch_conv_p0(const ConvK& k, const ConvCfg& c, hipStream_t st);
+hipError_t ddpm3d_launch_conv_p1(const ConvK& k, const ConvCfg& c, hipStream_t st);
+hipError_t ddpm3d_launch_conv_p2(const ConvK& k, const ConvCfg& c, hipStream_t st);
+
+hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) {
+    switch (c.PREC) {
+        case 0: return ddpm3d_launch_conv_p0(k, c, st);
+        case 1: return ddpm3d_launch_conv_p1(k, c, st);
+        case 2: return ddpm3d_launch_conv_p2(k, c, st);
+    }
+    return hipErrorInvalidValue;
+}
+#endif  // DDPM3D_PREC_ONLY == 0
+
 // ---------------------------------------------------------------- dispatch
 template <int PREC, int PIPE, int KS, int WN, int MT, int TXL, int TYL>
 static hipError_t launch_cfg(const ConvK& k, int grid_x, int grid_y, hipStream_t st) {
@@ -454,13 +485,14 @@ static hipError_t launch_cfg(const ConvK& k, int grid_x, int grid_y, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) {
+#define DDPM3D_CAT2(a, b) a##b
+#define DDPM3D_CAT(a, b) DDPM3D_CAT2(a, b)
+hipError_t DDPM3D_CAT(ddpm3d_launch_conv_p, DDPM3D_PREC_ONLY)(const ConvK& k, const ConvCfg& c, hipStream_t st) {
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     const int gy = (k.CoutPad + 32 * c.WN - 1) / (32 * c.WN);
     const int pipe = (k.in_mode == DDPM3D_IN_SAME || k.in_mode == DDPM3D_IN_UP) ? 1 : 0;
 #define CASE(P_, PI_, KS_, WN_, MT_, TXL_, TYL_)                                                      \
-    if (c.PREC == P_ && pipe == PI_ && c.KS == KS_ && c.WN == WN_ && c.MT == MT_ && c.TXL == TXL_ &&  \
-        c.TYL == TYL_)                                                                                \
+    if (pipe == PI_ && c.KS == KS_ && c.WN == WN_ && c.MT == MT_ && c.TXL == TXL_ && c.TYL == TYL_)   \
         return launch_cfg<P_, PI_, KS_, WN_, MT_, TXL_, TYL_>(k, gx, gy, st);
 #define CASES(P_, PI_)                                                                          \
     CASE(P_, PI_, 3, 4, 8, 3, 3)                                                                \
@@ -469,9 +501,9 @@ hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) 
     CASE(P_, PI_, 1, 4, 4, 3, 3) CASE(P_, PI_, 1, 2, 2, 3, 3) CASE(P_, PI_, 1, 1, 1, 3, 3)      \
     CASE(P_, PI_, 1, 4, 4, 2, 2) CASE(P_, PI_, 1, 2, 2, 2, 2) CASE(P_, PI_, 1, 1, 1, 2, 2)
 #ifdef DDPM3D_ONLY_ONE  // (compile-time experiments: a single instantiation)
-    CASE(1, 1, 3, 4, 4, 3, 3)
+    CASE(DDPM3D_PREC_ONLY, 1, 3, 4, 4, 3, 3)
 #else
-    CASES(0, 1) CASES(1, 1) CASES(0, 0) CASES(1, 0)
+    CASES(DDPM3D_PREC_ONLY, 1) CASES(DDPM3D_PREC_ONLY, 0)
 #endif
 #undef CASES
 #undef CASE

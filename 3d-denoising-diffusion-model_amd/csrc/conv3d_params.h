@@ -116,7 +116,7 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
 // f16 [tap][ci/16][hi|lo][CoutPad][16] followed by CoutPad fp32 output scales for PREC 1
 static inline size_t ddpm3d_packed_bytes(int Cout, int Cin, int ksize, int prec) {
     const size_t body = (size_t)ksize * ksize * ksize * ddpm3d_cin_pad(Cin) * ddpm3d_cout_pad(Cout) * 4;
-    return prec == 1 ? body + (size_t)ddpm3d_cout_pad(Cout) * 4 : body;
+    return prec != 0 ? body + (size_t)ddpm3d_cout_pad(Cout) * 4 : body;  // modes 1 and 2 share the image
 }
 
 hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st);

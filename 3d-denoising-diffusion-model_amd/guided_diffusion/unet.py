@@ -229,12 +229,17 @@ class UNetModel_noatt(nn.Module):
 
     # ---- precision switches (unet.py:999-1013) -------------------------------
     def convert_to_fp16(self):
-        warnings.warn("convert_to_fp16(): the HIP engine currently computes the torso in fp32 "
-                      "(a superset of the reference's fp16 precision); parameters are left in fp32")
+        """The reference halves the conv weights of the torso and feeds fp16 activations
+        (fp32 GroupNorm, fp32 time-embed / emb_layers / final conv).  Here: every conv's
+        operands are rounded to f16 on their way into the matrix cores (one f16 MFMA per
+        product), accumulation, storage, GroupNorm and the timestep path stay fp32.
+        Parameters keep their fp32 storage (`state_dict` is unchanged)."""
         self.dtype = torch.float16
+        self.conv_precision = "f16"
 
     def convert_to_fp32(self):
         self.dtype = torch.float32
+        self.conv_precision = os.environ.get("DDPM3D_PRECISION", "f16x3")
 
     # ---- engine management ----------------------------------------------------
     def _params_key(self):

@@ -43,6 +43,17 @@ PUBLISHED = dict(large_size=96, small_size=96, num_channels=128, num_res_blocks=
 TINY = dict(PUBLISHED, num_channels=32, num_res_blocks=1)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: f16/bf16 MFMA, dense
+# precision -> (dtype field, description of the conv arithmetic, basis of the roofline peak)
+ARITH = {
+    "f32": ("f32", "exact fp32 MFMA", "fp32 MFMA dense"),
+    "f16x3": ("f32 (conv products: 3x f16-split MFMA, f32 accumulate)",
+              "fp32 data/accumulators; each product of the convs = 3 f16 MFMAs on hi/lo-split "
+              "operands (error below fp32 accumulation error)",
+              "f16 MFMA dense (2500) / 3 MFMAs per algorithmic fp32 product"),
+    "f16": ("f16 operands, f32 accumulate/storage",
+            "conv operands rounded to f16 (one MFMA per product), fp32 accumulation, storage, "
+            "GroupNorm and timestep path: the reference's --use_fp16 analogue", "f16 MFMA dense"),
+}
 
 
 def log(*a):
@@ -107,31 +118,55 @@ def main():
     ap.add_argument("--arch", choices=["published", "tiny"], default="published")
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for cpu_baseline")
-    ap.add_argument("--precision", choices=["f32", "f16x3"], default=os.environ.get("DDPM3D_PRECISION", "f16x3"),
-                    help="arithmetic of the 3x3x3 conv products (both keep fp32 data and accumulators)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--precision", choices=["f32", "f16x3", "f16"],
+                    default=os.environ.get("DDPM3D_PRECISION", "f16x3"),
+                    help="arithmetic of the conv products (all keep fp32 data and accumulators); "
+                         "f16 = the reference's --use_fp16 analogue (BASELINE config 4)")
+    ap.add_argument("--sampler", choices=["ddpm", "ddim"], default="ddpm",
+                    help="ddim: --ddpm-steps DDIM steps (timestep_respacing ddimN, eta 0)")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE JSON line.  Libraries (RCCL prints a version banner) write to
+    # fd 1 directly, so fd 1 is pointed at stderr for the run and the result goes to the saved fd.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # --dist-backend gloo --share-gpu: rehearsal of the multi-rank flow on a one-GPU box (all
+    # ranks on cuda:0, collectives through host memory).  The real runs use RCCL ("nccl").
+    gloo = args.dist_backend == "gloo"
+    dev_index = 0 if args.share_gpu else local
+    # a process group also for one rank when launched under torch.distributed.run with
+    # DDPM3D_BENCH_FORCE_DIST=1 (exercises the RCCL code path on a one-GPU box)
+    use_dist = world > 1 or (os.environ.get("DDPM3D_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        torch.cuda.set_device(dev_index)
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     if args.gpus != world:
         log("[bench] note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
+    coll_dev = torch.device("cpu") if gloo else device
 
     from guided_diffusion import synth
     arch = PUBLISHED if args.arch == "published" else TINY
-    respacing = str(args.ddpm_steps)
+    respacing = ("ddim%d" % args.ddpm_steps) if args.sampler == "ddim" else str(args.ddpm_steps)
     model, diff, sd = build_model(arch, respacing, device)
     model.conv_precision = args.precision
-    # roofline peak for the dominant kernel's arithmetic: fp32 MFMA, or f16 MFMA / 3
-    # (three f16 MFMAs per algorithmic fp32 product)
-    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS / 3.0
+    # roofline peak for the dominant kernel's arithmetic: fp32 MFMA; f16 MFMA / 3 (three f16
+    # MFMAs per algorithmic fp32 product); f16 MFMA (one per product)
+    peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0,
+            "f16": PEAK_F16_MFMA_TFLOPS}[args.precision]
     B, S = args.batch, args.size
     shape = (B, 1, S, S, S)
     lr = torch.from_numpy(np.stack([synth.synth_low_res((1, S, S, S), seed=1234 + rank * 1000 + b)
@@ -150,18 +185,20 @@ def main():
         timing = []
         k = 0
         final = None
-        for final in diff.p_sample_loop_progressive(model, shape, noise, model_kwargs={"low_res": lr}):
+        loop = diff.ddim_sample_loop_progressive if args.sampler == "ddim" else diff.p_sample_loop_progressive
+        for final in loop(model, shape, noise, model_kwargs={"low_res": lr}):
             k += 1
             plan.timing = timing if (measure and k == T // 2) else None   # instrument ONE forward
         plan.timing = None
         sample = final["sample"]
-        if world > 1:
-            gathered = [torch.empty_like(sample) for _ in range(world)]
-            dist.all_gather(gathered, sample)
+        if use_dist:
+            mine = sample.to(coll_dev)
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
         return sample, timing
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -182,8 +219,8 @@ def main():
             log("[bench] step %d done at %.2fs" % (s, time.time() - t_start))
     sync()
     elapsed = time.time() - t_start
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if use_dist:
+        tt = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(sample).all()
@@ -206,8 +243,7 @@ def main():
         roof = {
             "bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-            "peak_basis": ("fp32 MFMA dense" if args.precision == "f32" else
-                           "f16 MFMA dense (2500) / 3 MFMAs per algorithmic fp32 product"),
+            "peak_basis": ARITH[args.precision][2],
             "launches_timed": cnt, "avg_launch_ms": round(ms / cnt, 4),
             "all_conv_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                  "ms_per_forward": round(tot_ms / max(1, args.steps), 3),
@@ -219,7 +255,8 @@ def main():
     if rank == 0:
         vols = args.steps * B * world
         res = {
-            "metric": "denoised 64^3 volumes/sec @250 DDPM steps",
+            "metric": ("denoised 64^3 volumes/sec @250 DDPM steps" if args.sampler == "ddpm" and T == 250
+                       else "denoised %d^3 volumes/sec @%d %s steps" % (S, T, args.sampler.upper())),
             "value": vols / elapsed,
             "unit": "volumes/s",
             "n_gpus": world,
@@ -231,17 +268,16 @@ def main():
             "vs_baseline": None,
             # fp32 tensors and accumulators in both modes; f16x3 = every fp32 product of the 3x3x3
             # convs formed as three f16 MFMAs on hi/lo-split operands (fp32-grade error, see tests)
-            "dtype": "f32" if args.precision == "f32" else "f32 (conv products: 3x f16-split MFMA, f32 accumulate)",
+            "dtype": ARITH[args.precision][0],
             "data": "synthetic",
-            "config": {"workload": "%dx1x%d^3 volume(s) per GPU, %d DDPM steps, %s architecture "
+            "config": {"workload": "%dx1x%d^3 volume(s) per GPU, %d %s steps, %s architecture "
                                    "(SuperResModel_noatt, %d base ch, mult (1,1,2,3,4), %d res blocks, "
                                    "learn_sigma), seeded random weights, device RNG"
-                                   % (B, S, T, args.arch, arch["num_channels"], arch["num_res_blocks"]),
+                                   % (B, S, T, args.sampler.upper(), args.arch, arch["num_channels"],
+                                      arch["num_res_blocks"]),
                        "parallelism": "independent volumes per rank (dp%d), all_gather of finished samples" % world,
                        "tflop_per_volume": round(flops_fwd * T / B / 1e12, 1),
-                       "conv_arithmetic": ("exact fp32 MFMA" if args.precision == "f32" else
-                                           "fp32 data/accumulators; each product of the 3x3x3 convs = 3 f16 "
-                                           "MFMAs on hi/lo-split operands (error below fp32 accumulation error)")},
+                       "conv_arithmetic": ARITH[args.precision][1]},
             "roofline": roof,
         }
         if world == 1 and args.cpu_steps > 0:
@@ -257,8 +293,9 @@ def main():
             res["cpu_baseline"] = cpu_baseline(arch, sd_cpu, S, respacing, args.cpu_steps, threads)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -120,14 +120,18 @@ int ddpm3d_abi_version(void);
 const char* ddpm3d_last_error(void);
 
 /* Arithmetic of the convolution's products.  Inputs, outputs and accumulators are
- * fp32 in both modes.
- *   DDPM3D_PREC_F32    v_mfma_f32_32x32x2_f32: exact fp32 products.
+ * fp32 in every mode.
+ *   DDPM3D_PREC_F32   v_mfma_f32_32x32x2_f32: exact fp32 products.
  *   DDPM3D_PREC_F16X3  every fp32 operand x is split hi + lo into two f16 (after a
  *                      power-of-two scaling) and a*b = hi*hi + hi*lo + lo*hi on
  *                      v_mfma_f32_32x32x16_f16 (each f16xf16 product is exact in
  *                      fp32).  Operand representation error ~2^-23, i.e. below the
- *                      fp32 accumulation error both modes share; 16/3 the MFMA rate. */
-enum { DDPM3D_PREC_F32 = 0, DDPM3D_PREC_F16X3 = 1 };
+ *                      fp32 accumulation error both modes share; 16/3 the MFMA rate.
+ *   DDPM3D_PREC_F16   one f16 MFMA per product on the f16-ROUNDED (scaled) operands,
+ *                      fp32 accumulate: the analogue of the reference's --use_fp16 torso
+ *                      (unet.py:999-1005, fp16_util.py:15-22); ~2^-11 operand error, judged
+ *                      by PSNR, not by the 1e-3 parity bar.  Same packed image as F16X3. */
+enum { DDPM3D_PREC_F32 = 0, DDPM3D_PREC_F16X3 = 1, DDPM3D_PREC_F16 = 2 };
 
 /* bytes of the packed form of an (Cout, Cin, k, k, k) weight for a precision mode */
 size_t ddpm3d_packed_weight_bytes(int Cout, int Cin, int ksize, int precision);

@@ -126,6 +126,25 @@ def test_sampler_loop_f16x3_vs_reference_golden(golden):
     assert rel_err(out.cpu().numpy(), golden("sampler.npz")["ddpm10_32/sample"]) < 1e-3
 
 
+def test_convert_to_fp16_ddim_psnr(golden):
+    """BASELINE config 4 shape of run (DDIM respaced sampler, half-precision conv operands) on the
+    tiny net: model.convert_to_fp16() as scripts/test.py:33-34 calls it.  Judged by PSNR against
+    the fp32 reference output, not by the fp32 parity bar."""
+    model, diff = build(TINY, "ddim10")
+    model.convert_to_fp16()
+    assert model.dtype == torch.float16 and model.conv_precision == "f16"
+    shape = (2, 1, 8, 16, 16)
+    draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, 11, seed=10)]
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234)).cuda()
+    out = diff.ddim_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
+    ref = golden("sampler.npz")["ddim10_8x16x16/sample"]
+    mse = float(((out.cpu().numpy() - ref) ** 2).mean())
+    psnr = 10 * np.log10(4.0 / mse)            # data range [-1, 1]
+    assert psnr > 35.0, psnr
+    assert set(model.state_dict()) == set(build(TINY)[0].state_dict())   # parameters stay fp32 / same keys
+    assert all(v.dtype == torch.float32 for v in model.state_dict().values())
+
+
 def test_p_sample_loop_api_and_determinism():
     """Positional noise argument as scripts/test.py:63-69 passes it; result shape/dtype/device;
     bitwise repeatability with injected noise (no atomics anywhere in the path)."""

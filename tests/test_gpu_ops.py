@@ -103,6 +103,25 @@ def test_conv3d_f16x3_accuracy_is_fp32_grade(hc):
     assert errs[1] < 2 * errs[0] + 2e-7, errs
 
 
+def test_conv3d_f16_mode_is_half_precision_grade(hc):
+    """precision 2 (one f16 MFMA per product, the --use_fp16 analogue): operands carry 11 bits,
+    so the bar is ~1e-3 of the output range, far above the fp32 modes and far below 'wrong'."""
+    x = rnd(1, 64, 4, 16, 16, seed=21)
+    w = rnd(128, 64, 3, 3, 3, seed=22, scale=0.03)
+    b = rnd(128, seed=23)
+    ref = F.conv3d(x, w, b, padding=1)
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (4, 16, 16), precision=2)
+    e = rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy())
+    assert 1e-6 < e < 2e-3, e
+    # integer data is exact in f16 too: same mapping as the other modes
+    g = np.random.default_rng(5)
+    xi = torch.from_numpy(g.integers(-3, 4, (1, 16, 3, 9, 10)).astype(np.float32))
+    wi = torch.from_numpy(g.integers(-2, 3, (40, 16, 3, 3, 3)).astype(np.float32))
+    bi = torch.from_numpy(g.integers(-5, 6, (40,)).astype(np.float32))
+    out, _, _ = hc.conv3d([hc.to_ndhwc(xi).cuda()], wi.cuda(), bi.cuda(), (3, 9, 10), precision=2)
+    assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(xi, wi, bi, padding=1))
+
+
 def test_conv3d_k1_concat(hc):
     xa, xb = rnd(2, 32, 3, 8, 8, seed=1), rnd(2, 16, 3, 8, 8, seed=2)
     w = rnd(64, 48, 1, 1, 1, seed=3, scale=0.1)
