@@ -237,7 +237,12 @@ class GaussianDiffusion:
                     out = eng.forward(img, low_res, film[i], 0)
                 else:
                     out = self._call_model(model, img, t, model_kwargs)
-                z = step_noise[k] if step_noise is not None else th.randn_like(img)
+                if step_noise is None:
+                    z = th.randn_like(img)
+                elif callable(step_noise):
+                    z = step_noise(k, img)       # e.g. per-volume generators (scripts/test.py)
+                else:
+                    z = step_noise[k]
                 res = self._update(kind, out, img, t, z, clip_denoised, eta)
                 yield res
                 img = res["sample"]

@@ -1,0 +1,69 @@
+"""
+Patch tiler / Hann stitcher / volume I/O (guided_diffusion/patches.py).
+PARITY UNPINNED against the reference (scripts/test.py cannot be imported here
+and holds no fixtures): checked against the constants its source states and
+against invariants of the algorithm.
+"""
+
+import numpy as np
+import pytest
+
+from guided_diffusion import patches
+
+
+def test_start_positions_match_the_reference_constants():
+    assert patches.xy_starts(200, 96, 3) == [0, 52, 104]            # scripts/test.py:285-286
+    assert patches.xy_starts(150, 96, 3) == [0, 27, 54]             # int(i * (150-96)/2)
+    assert patches.xy_starts(96, 96, 1) == [0]
+    assert patches.z_starts(90, 96) == [0] and patches.z_starts(96, 96) == [0]
+    assert patches.z_starts(130, 96) == [0, 34]
+    grid = patches.patch_grid((110, 200, 200), 96)
+    assert len(grid) == 18 and grid[0] == (0, 0, 0) and grid[1] == (0, 0, 14) and grid[2] == (0, 52, 0)
+
+
+def test_split_pads_and_orders_like_the_reference():
+    rng = np.random.default_rng(0)
+    vol = rng.random((110, 200, 200), dtype=np.float32)              # (D, H, W)
+    p, grid = patches.split_volume(vol, 96)
+    assert p.shape == (18, 1, 96, 96, 96) and p.dtype == np.float32
+    xs, ys, zs = grid[7]
+    assert np.array_equal(p[7, 0], vol[zs:zs + 96, xs:xs + 96, ys:ys + 96])
+    # a short volume is zero padded along Z
+    p2, g2 = patches.split_volume(vol[:90], 96)
+    assert len(g2) == 9 and np.all(p2[:, :, 90:] == 0) and np.array_equal(p2[0, 0, :90], vol[:90, :96, :96])
+    assert patches.split_volume(vol[None], 96)[0].shape == p.shape    # leading singleton dropped
+    with pytest.raises(ValueError):
+        patches.split_volume(np.zeros((4, 4)), 96)
+
+
+def test_hann_window():
+    w = patches.hann_window_3d(96)
+    assert w.shape == (96, 96, 96) and w.max() == 1.0 and w.min() == 0.0
+    h = np.hanning(96)
+    assert np.allclose(w[10, 20, 30], h[10] * h[20] * h[30] / (h.max() ** 3))
+
+
+def test_stitch_is_a_partition_of_unity_inside_the_border():
+    """Identity 'denoiser': stitching the input's own patches returns the input wherever the
+    total weight is positive; the outermost planes (Hann weight 0) stay 0 as in the reference."""
+    rng = np.random.default_rng(1)
+    vol = rng.random((110, 200, 200), dtype=np.float32)
+    p, grid = patches.split_volume(vol, 96)
+    as_hwz = [q[0].transpose(1, 2, 0) for q in p]                     # (Z,H,W) -> (H,W,Z), scripts/test.py:72
+    out, wsum = patches.stitch_patches(as_hwz, grid, vol.shape, 96)
+    assert out.shape == (200, 200, 110)
+    ref = vol.transpose(1, 2, 0)
+    inner = wsum > 0
+    assert np.allclose(out[inner], ref[inner], atol=1e-5)
+    assert np.all(out[~inner] == 0) and not inner[0].any() and not inner[:, :, 0].any()
+    assert inner[1:-1, 1:-1, 1:-1].all()                              # only the outer shell has zero weight
+
+
+def test_volume_io_round_trip(tmp_path):
+    vol = np.arange(4 * 5 * 6, dtype=np.float32).reshape(4, 5, 6)
+    np.savez(tmp_path / "a.npz", vol)
+    np.save(tmp_path / "b.npy", vol[None])
+    assert np.array_equal(patches.load_volume(str(tmp_path / "a.npz")), vol)
+    assert np.array_equal(patches.load_volume(str(tmp_path / "b.npy")), vol)
+    with pytest.raises(ValueError):
+        patches.load_volume(str(tmp_path / "c.txt"))
