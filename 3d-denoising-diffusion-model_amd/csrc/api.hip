@@ -183,6 +183,14 @@ int ddpm3d_ndhwc_to_ncdhw(const float* in, int N, int C, int voxels, float* out,
     return launched(ddpm3d_launch_transpose(in, N, voxels, C, out, (hipStream_t)stream), "ndhwc_to_ncdhw");
 }
 
+int ddpm3d_attention(const float* qkv, int N, int T, int heads, int head_channels, float* out, void* stream) {
+    if (!qkv || !out || N <= 0 || T <= 0 || heads <= 0) return fail(DDPM3D_EINVAL, "attention: bad arguments");
+    if (head_channels != 32 && head_channels != 64 && head_channels != 128)
+        return fail(DDPM3D_ENOSUP, "attention: %d channels per head (32, 64 or 128 are built)", head_channels);
+    if (!aligned16(qkv) || !aligned16(out)) return fail(DDPM3D_EINVAL, "attention: buffers must be 16-byte aligned");
+    return launched(ddpm3d_launch_attention(qkv, N, T, heads, head_channels, out, (hipStream_t)stream), "attention");
+}
+
 static int step_args_ok(const float* mo, const float* x, const float* noise, const float* coef,
                         const int64_t* t, int N, int voxels, float* sample) {
     return mo && x && noise && coef && t && sample && N > 0 && voxels > 0;

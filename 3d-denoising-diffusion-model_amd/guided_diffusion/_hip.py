@@ -23,7 +23,7 @@ F_LEARN_SIGMA, F_PREDICT_XSTART, F_CLIP = 1, 2, 4
 NCOEF = 8
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _fp = C.c_void_p
 
@@ -56,6 +56,7 @@ EXPORTS = {
     "ddpm3d_gn_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_timestep_embedding": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ddpm3d_linear": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp, C.c_int, _fp]),
+    "ddpm3d_attention": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_ncdhw_to_ndhwc": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_ndhwc_to_ncdhw": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_p_sample_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),

@@ -20,10 +20,11 @@ import torch
 import torch.distributed as dist
 
 
-def setup_dist(backend=None):
+def setup_dist(backend=None, init_method=None):
     """Initialise the default process group from the torchrun environment
-    (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT).  A single
-    process (WORLD_SIZE unset or 1) needs no group, like dist_util.py:29-31."""
+    (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT; or an explicit
+    `init_method` such as file://...).  A single process (WORLD_SIZE unset or 1)
+    needs no group, like dist_util.py:29-31."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 or dist.is_initialized():
         if torch.cuda.is_available():
@@ -33,12 +34,15 @@ def setup_dist(backend=None):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (required on this stack)
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
+    extra = {}
+    if init_method is not None:
+        extra = dict(init_method=init_method, rank=int(os.environ["RANK"]), world_size=world)
     if backend == "nccl":
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), **extra)
     else:
-        dist.init_process_group(backend)
+        dist.init_process_group(backend, **extra)
 
 
 def rank():

@@ -291,15 +291,35 @@ class _Plan:
             self.conv_step(pc, [x], y, in_mode=H.IN_UP)
             return y
         if e.kind == "attn":
-            raise NotImplementedError(
-                "attention blocks (AttentionBlock, unet.py:259-305) are not yet available in the "
-                "HIP engine; the published model (SuperResModel_noatt with "
-                "--attention_resolutions 1000) has none")
+            return self.attention(e, srcs[0])
         if e.kind == "downconv":
             raise NotImplementedError(
                 "strided-conv Downsample (resblock_updown=False) is not yet available in the HIP "
                 "engine; the published model uses --resblock_updown True")
         raise ValueError(e.kind)
+
+    def attention(self, e, x):
+        """AttentionBlock (unet.py:296-305): x + proj_out(attn(qkv(norm(x)))) as
+        gn_finalize -> 1x1 conv (GroupNorm prologue, no activation) -> streaming attention
+        -> 1x1 conv (+ residual x, + statistics for the next GroupNorm)."""
+        eng, N = self.eng, self.N
+        p = e.prefix
+        heads = e.heads
+        Cn = x.C
+        if Cn % heads:
+            raise RuntimeError("attention: %d channels not divisible by %d heads" % (Cn, heads))
+        ch = Cn // heads
+        if ch not in (32, 64, 128):
+            raise NotImplementedError("attention with %d channels per head (32, 64 or 128 are built)" % ch)
+        A, B = self.finalize([x], p + ".norm", None)
+        qkv = self.new_act(3 * Cn, x.D, x.H, x.W)
+        self.conv_step(eng.conv[p + ".qkv"], [x], qkv, aff=(A, B), act=H.ACT_NONE, want_stats=False)
+        a = self.new_act(Cn, x.D, x.H, x.W)
+        self.steps.append((eng.lib.ddpm3d_attention,
+                           [H.ptr(qkv.buf), N, x.voxels, heads, ch, H.ptr(a.buf), 0]))
+        y = self.new_act(Cn, x.D, x.H, x.W)
+        self.conv_step(eng.conv[p + ".proj_out"], [a], y, res=x, res_mode=H.RES_SAME)
+        return y
 
     def resblock(self, e, srcs):
         eng = self.eng

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DDPM3D_ABI_VERSION 3
+#define DDPM3D_ABI_VERSION 4
 
 enum {
     DDPM3D_OK = 0,
@@ -178,6 +178,16 @@ int ddpm3d_timestep_embedding(const float* t, int rows, int dim, const float* fr
  * out[r][o] = bias[o] + sum_k f(in[r][k]) * w[o][k],  f = SiLU if silu_in */
 int ddpm3d_linear(const float* in, int rows, int K, const float* w, const float* bias,
                   int O, int silu_in, float* out, int out_stride, void* stream);
+
+/*
+ * Self-attention core of AttentionBlock (unet.py:296-305) with the legacy head layout
+ * (QKVAttentionLegacy, unet.py:337-354): qkv = [N][T][heads*3*ch] (per head: q | k | v),
+ * out = [N][T][heads*ch];  out = softmax_fp32((q s)^T (k s)) v^T with s = ch^-1/4.
+ * Streaming softmax: the T x T weight matrix the reference materialises (:349-353) never
+ * exists.  The GroupNorm and the qkv / proj_out 1x1 convs around it are ddpm3d_conv3d calls.
+ */
+int ddpm3d_attention(const float* qkv, int N, int T, int heads, int head_channels,
+                     float* out, void* stream);
 
 /* layout changes at the API edge */
 int ddpm3d_ncdhw_to_ndhwc(const float* in, int N, int C, int voxels, float* out, void* stream);

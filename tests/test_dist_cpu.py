@@ -27,10 +27,10 @@ def _fake_denoise(index):
     return torch.randn(1, 1, 4, 4, 4, generator=g) + index
 
 
-def _worker(rank, world, port, n_items, q):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist_util.setup_dist(backend="gloo")
+def _worker(rank, world, rdv_file, n_items, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    # file rendezvous: no TCP port to race for when the whole suite runs
+    dist_util.setup_dist(backend="gloo", init_method="file://" + rdv_file)
     assert dist_util.rank() == rank and dist_util.world_size() == world
     mine = dist_util.partition(n_items)
     collected = []
@@ -51,12 +51,12 @@ def test_partition_rule():
     assert allv == list(range(18))
 
 
-def test_two_ranks_gloo_match_single_process():
+def test_two_ranks_gloo_match_single_process(tmp_path):
     n_items = 5                                    # uneven on purpose
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    rdv = str(tmp_path / "rendezvous")
+    procs = [ctx.Process(target=_worker, args=(r, 2, rdv, n_items, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

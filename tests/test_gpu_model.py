@@ -72,6 +72,34 @@ def test_unet_forward_published_architecture(golden, precision):
     assert rel_err(y.cpu().numpy(), golden("unet_forward.npz")["published_8x32x32"]) < 1e-4
 
 
+def test_unet_with_level_attention_vs_reference_golden(golden):
+    """attention_resolutions='8,4' on the factory's (_noatt) class: AttentionBlocks after the
+    ResBlocks at ds 4 and 8 (2 and 3 heads of 32 channels), encoder and decoder."""
+    model, _ = build(dict(TINY, large_size=32, attention_resolutions="8,4", num_head_channels=32))
+    x, lr = inputs((1, 1, 8, 32, 32))
+    with torch.no_grad():
+        y = model(x.cuda(), torch.tensor([10]).cuda(), low_res=lr.cuda())
+    assert rel_err(y.cpu().numpy(), golden("unet_forward.npz")["tiny_attn"]) < 1e-4
+
+
+def test_unet_with_mid_block_attention_vs_reference_golden(golden):
+    """SuperResModel / UNetModel (unet.py:396-716, 1655-1673): the variant north_star names,
+    with the AttentionBlock between the two middle ResBlocks.  Built directly, as the golden was
+    (sr_create_model only returns the _noatt class)."""
+    from guided_diffusion.unet import SuperResModel
+    model = SuperResModel(image_size=32, in_channels=1, model_channels=32, out_channels=2, num_res_blocks=1,
+                          attention_resolutions=(1000,), channel_mult=(1, 1, 2, 3, 4), dims=3,
+                          num_head_channels=32, use_scale_shift_norm=True, resblock_updown=True)
+    sd = model.state_dict()
+    assert "middle_block.1.qkv.weight" in sd and "middle_block.2.in_layers.2.weight" in sd
+    model.load_state_dict({k: torch.from_numpy(synth.synth_param(k, tuple(v.shape))) for k, v in sd.items()})
+    model.to("cuda").eval()
+    x, lr = inputs((1, 1, 4, 32, 32))
+    with torch.no_grad():
+        y = model(x.cuda(), torch.tensor([77]).cuda(), low_res=lr.cuda())
+    assert rel_err(y.cpu().numpy(), golden("unet_forward.npz")["tiny_midattn"]) < 1e-4
+
+
 def test_unet_forward_vs_oracle_layerwise():
     """Same weights through oracle/unet_ref.py; also a size no golden covers."""
     from oracle import unet_ref

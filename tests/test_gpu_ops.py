@@ -311,6 +311,33 @@ def test_linear_and_timestep_embedding(hc):
         assert rel_err(o.cpu().numpy(), ref.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("N,T,heads,ch", [(1, 128, 2, 32), (2, 200, 3, 64), (1, 77, 1, 32), (1, 512, 2, 64)])
+def test_attention_core_vs_legacy_reference(hc, N, T, heads, ch):
+    """Streaming attention vs the materialised softmax of QKVAttentionLegacy (unet.py:337-354),
+    including T not a multiple of the 32-key tile or the 128-query block."""
+    import math
+    import guided_diffusion._hip as H
+    lib = H.load()
+    qkv = rnd(N, heads * 3 * ch, T, seed=1)                      # reference layout (N, H*3*C, T)
+    q, k, v = qkv.reshape(N * heads, ch * 3, T).split(ch, dim=1)
+    s = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s).float(), dim=-1)
+    ref = torch.einsum("bts,bcs->bct", w, v).reshape(N, -1, T)    # (N, H*C, T)
+    qd = qkv.permute(0, 2, 1).contiguous().cuda()                 # channels-last (N, T, H*3*C)
+    out = torch.full((N, T, heads * ch), float("nan"), device="cuda")
+    H.check(lib.ddpm3d_attention(H.ptr(qd), N, T, heads, ch, H.ptr(out), H.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(out.permute(0, 2, 1).cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_attention_rejects_unsupported_head_width(hc):
+    import guided_diffusion._hip as H
+    lib = H.load()
+    x = torch.zeros(1, 16, 3 * 8, device="cuda")
+    assert lib.ddpm3d_attention(H.ptr(x), 1, 16, 1, 8, H.ptr(x), H.stream()) == -3
+    assert b"channels per head" in lib.ddpm3d_last_error()
+
+
 def test_layout_round_trip(hc):
     import guided_diffusion._hip as H
     lib = H.load()
