@@ -315,6 +315,8 @@ class _Plan:
         qkv = self.new_act(3 * Cn, x.D, x.H, x.W)
         self.conv_step(eng.conv[p + ".qkv"], [x], qkv, aff=(A, B), act=H.ACT_NONE, want_stats=False)
         a = self.new_act(Cn, x.D, x.H, x.W)
+        # two T x T x ch products per head (the reference's count_flops_attn, unet.py:308-325)
+        self.conv_meta[len(self.steps)] = ("attention_ch%d" % ch, 4.0 * N * heads * float(x.voxels) ** 2 * ch)
         self.steps.append((eng.lib.ddpm3d_attention,
                            [H.ptr(qkv.buf), N, x.voxels, heads, ch, H.ptr(a.buf), 0]))
         y = self.new_act(Cn, x.D, x.H, x.W)

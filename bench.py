@@ -124,6 +124,9 @@ def main():
                     default=os.environ.get("DDPM3D_PRECISION", "f16x3"),
                     help="arithmetic of the conv products (all keep fp32 data and accumulators); "
                          "f16 = the reference's --use_fp16 analogue (BASELINE config 4)")
+    ap.add_argument("--large-size", type=int, default=None, help="override the factory's large_size flag")
+    ap.add_argument("--attention-resolutions", default=None,
+                    help="override, e.g. '16' with --large-size 128 --size 128 = BASELINE config 5")
     ap.add_argument("--sampler", choices=["ddpm", "ddim"], default="ddpm",
                     help="ddim: --ddpm-steps DDIM steps (timestep_respacing ddimN, eta 0)")
     args = ap.parse_args()
@@ -159,7 +162,11 @@ def main():
     coll_dev = torch.device("cpu") if gloo else device
 
     from guided_diffusion import synth
-    arch = PUBLISHED if args.arch == "published" else TINY
+    arch = dict(PUBLISHED if args.arch == "published" else TINY)
+    if args.large_size is not None:
+        arch.update(large_size=args.large_size, small_size=args.large_size)
+    if args.attention_resolutions is not None:
+        arch.update(attention_resolutions=args.attention_resolutions)
     respacing = ("ddim%d" % args.ddpm_steps) if args.sampler == "ddim" else str(args.ddpm_steps)
     model, diff, sd = build_model(arch, respacing, device)
     model.conv_precision = args.precision
