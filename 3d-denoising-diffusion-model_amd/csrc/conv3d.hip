@@ -28,19 +28,7 @@
 // (ops.hip) stores the order each mode reads.
 #include <hip/hip_runtime.h>
 #include "conv3d_load.h"
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
-// smallest x >= v with x % 16 == res
-constexpr int pad_to_residue(int v, int res) { return v + ((res - v % 16) + 16) % 16; }
-
-// LDS strides (in 16-byte slots) of the halo image; see the bank-conflict note in the kernel.
-template <int TX, int HX, int HY>
-struct LdsGeom {
-    static constexpr int RY = pad_to_residue(HX * 5, TX == 8 ? 8 : 4);
-    static constexpr int RZ = TX == 8 ? HY * RY : pad_to_residue(HY * RY, 0);
-};
+#include "conv3d_db.h"  // LdsGeom, conv_epilogue, and the double-buffered 3x3x3 variant
 
 // PIPE = 1: IN_SAME / IN_UP inputs, staging software-pipelined; PIPE = 0: IN_POOL / IN_PLANAR2.
 template <int PREC, int PIPE, int KS, int WN, int MT, int TXL, int TYL>
@@ -282,65 +270,8 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
 
     if (!wave_active) return;
 
-    // ---------------------------------------------------------- epilogue
-    // C/D map of 32x32 MFMA: col = lane&31 (cout), row = (reg&3) + 8*(reg>>2) + 4*half
-    const bool cvalid = cout < p.Cout;
-    const size_t DHW = (size_t)p.D * p.H * p.W;
-    // PREC 1: undo the operand scaling (exact: a power of two per cout)
-    const float oscale = (PREC != 0 && cvalid) ? p.wscale[cout] : 1.0f;
-    if (p.ksplit > 1) {
-        // split-K: raw partial sums to this split's slab; bias / residual / statistics
-        // are applied by the reduce kernel once all splits are in
-        float* slab = p.partial + ((size_t)blockIdx.z * p.N + n) * DHW * p.Cout;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                const int m = (wm * MT + t) * 32 + row;
-                const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
-                const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
-                if (cvalid && z < p.D && y < p.H && x < p.W)
-                    slab[(((size_t)z * p.H + y) * p.W + x) * p.Cout + cout] =
-                        PREC != 0 ? acc[t][reg] * oscale : acc[t][reg];
-            }
-        }
-        return;
-    }
-    const float bias = cvalid ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
-    float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-            const int m = (wm * MT + t) * 32 + row;
-            const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
-            const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
-            const bool ok = cvalid && z < p.D && y < p.H && x < p.W;
-            if (ok) {
-                float val = (PREC != 0 ? acc[t][reg] * oscale : acc[t][reg]) + bias;
-                const size_t vox = ((size_t)z * p.H + y) * p.W + x;
-                if (p.res_mode != DDPM3D_RES_NONE) val += ddpm3d_residual(p, n, z, y, x, cout);
-                if (p.out_layout == DDPM3D_OUT_NDHWC)
-                    p.out[((size_t)n * DHW + vox) * p.Cout + cout] = val;
-                else
-                    p.out[((size_t)n * p.Cout + cout) * DHW + vox] = val;
-                s1 += val;
-                s2 = fmaf(val, val, s2);
-            }
-        }
-    }
-    if (p.stats != nullptr) {
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (half == 0 && cvalid) {
-            const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-            const size_t row = (size_t)n * p.stats_rows + (size_t)tile_in_n * WM + wm;
-            float2 v2 = make_float2(s1, s2);
-            *reinterpret_cast<float2*>(p.stats + (row * p.Cout + cout) * 2) = v2;
-        }
-    }
+    const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
+    conv_epilogue<PREC, WM, MT, TXL, TYL>(p, acc, n, z0, y0, x0, tile_in_n, wm, cout, half);
 }
 
 // This file is compiled once per arithmetic mode (-DDDPM3D_PREC_ONLY=0|1|2, see the
@@ -384,7 +315,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) 
         }
         if (p.stats != nullptr) {
             float2 v2 = make_float2(s1, s2);
-            *reinterpret_cast<float2*>(p.stats + (((size_t)n * rows + r) * p.Cout + cout) * 2) = v2;
+            *reinterpret_cast<float2*>(p.stats + (((size_t)n * p.Cout + cout) * rows + r) * 2) = v2;
         }
     }
 }
@@ -442,7 +373,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK 
                                     (red[0][2][cq * 4 + c] + red[0][3][cq * 4 + c]);
                     const float b = (red[1][0][cq * 4 + c] + red[1][1][cq * 4 + c]) +
                                     (red[1][2][cq * 4 + c] + red[1][3][cq * 4 + c]);
-                    *reinterpret_cast<float2*>(p.stats + (((size_t)n * rows + r) * p.Cout + q * 4 + c) * 2) =
+                    *reinterpret_cast<float2*>(p.stats + (((size_t)n * p.Cout + q * 4 + c) * rows + r) * 2) =
                         make_float2(a, b);
                 }
             }
@@ -491,6 +422,34 @@ hipError_t DDPM3D_CAT(ddpm3d_launch_conv_p, DDPM3D_PREC_ONLY)(const ConvK& k, co
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     const int gy = (k.CoutPad + 32 * c.WN - 1) / (32 * c.WN);
     const int pipe = (k.in_mode == DDPM3D_IN_SAME || k.in_mode == DDPM3D_IN_UP) ? 1 : 0;
+    // Double-buffered variant (conv3d_db.h): 3x3x3, 128x128 tile, pipelined input, every wave
+    // active.  OPT-IN (DDPM3D_DBUF=1): measured on MI355X it is 0-4 % SLOWER than the
+    // single-buffer kernel (128->128 @ 64^3, f16x3: 331 vs 344 TFLOP/s) -- with three
+    // single-buffer workgroups per CU the staging phase is already hidden by the neighbours,
+    // and the second LDS image costs one resident workgroup.
+    {
+        static const bool dbuf_on = [] { const char* e = getenv("DDPM3D_DBUF"); return e && atoi(e) != 0; }();
+        if (dbuf_on && pipe && c.KS == 3 && c.WN == 4 && c.MT == 4 && k.CoutPad % 128 == 0) {
+            constexpr int P = DDPM3D_PREC_ONLY;
+            // two halo images = 71 680 B of dynamic LDS: above the 64 KiB default, so raise the cap once
+            if (c.TXL == 3) {
+                constexpr size_t lds = 2 * (size_t)4 * LdsGeom<8, 10, 10>::RZ * 16;
+                static const hipError_t attr = hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(&conv3d_db_kernel<P, 3, 3>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (attr != hipSuccess) return attr;
+                hipLaunchKernelGGL((conv3d_db_kernel<P, 3, 3>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+            } else {
+                constexpr size_t lds = 2 * (size_t)10 * LdsGeom<4, 6, 6>::RZ * 16;
+                static const hipError_t attr = hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(&conv3d_db_kernel<P, 2, 2>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (attr != hipSuccess) return attr;
+                hipLaunchKernelGGL((conv3d_db_kernel<P, 2, 2>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+            }
+            return hipGetLastError();
+        }
+    }
 #define CASE(P_, PI_, KS_, WN_, MT_, TXL_, TYL_)                                                      \
     if (pipe == PI_ && c.KS == KS_ && c.WN == WN_ && c.MT == MT_ && c.TXL == TXL_ && c.TYL == TYL_)   \
         return launch_cfg<P_, PI_, KS_, WN_, MT_, TXL_, TYL_>(k, gx, gy, st);

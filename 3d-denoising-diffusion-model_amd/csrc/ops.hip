@@ -122,13 +122,28 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const int Cs = from0 ? C0 : C1;
     const int rows = from0 ? rows0 : rows1;
     const int cs = from0 ? cbeg : cbeg - C0;
+    // statistics are channel-major [N][C][rows][2]: the group's cg channels x rows partial sums
+    // are ONE contiguous run of cg*rows float2, read with 16-byte loads
     double s1 = 0.0, s2 = 0.0;
-    const int items = rows * cg;
-    for (int i = threadIdx.x; i < items; i += blockDim.x) {
-        const int r = i / cg, c = i - r * cg;
-        const float2 v = *reinterpret_cast<const float2*>(st + (((size_t)n * rows + r) * Cs + cs + c) * 2);
-        s1 += (double)v.x;
-        s2 += (double)v.y;
+    const size_t items = (size_t)rows * cg;          // float2 count
+    const float* run = st + ((size_t)n * Cs + cs) * rows * 2;
+    if ((reinterpret_cast<uintptr_t>(run) & 15) == 0) {
+        const size_t pairs = items / 2;              // float4 = two (sum, sumsq) entries
+        for (size_t i = threadIdx.x; i < pairs; i += blockDim.x) {
+            const float4 v = *reinterpret_cast<const float4*>(run + i * 4);
+            s1 += (double)v.x + (double)v.z;
+            s2 += (double)v.y + (double)v.w;
+        }
+        if ((items & 1) && threadIdx.x == 0) {
+            s1 += (double)run[(items - 1) * 2];
+            s2 += (double)run[(items - 1) * 2 + 1];
+        }
+    } else {                                         // odd rows x odd channel offset: 8-byte aligned only
+        for (size_t i = threadIdx.x; i < items; i += blockDim.x) {
+            const float2 v = *reinterpret_cast<const float2*>(run + i * 2);
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
     }
     __shared__ double red[2][4];
     s1 = wave_sum(s1);
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
                     a += sh[0][(l * qpt + threadIdx.x) * 4 + i];
                     b += sh[1][(l * qpt + threadIdx.x) * 4 + i];
                 }
-                float* o = stats + (((size_t)n * rows + r) * C + q * 4 + i) * 2;
+                float* o = stats + (((size_t)n * C + q * 4 + i) * rows + r) * 2;
                 o[0] = a;
                 o[1] = b;
             }

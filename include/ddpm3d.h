@@ -108,7 +108,7 @@ typedef struct ddpm3d_conv_desc {
     float* out;
     int32_t out_layout;     /* DDPM3D_OUT_*                                          */
     int32_t stats_rows;     /* rows per sample of `stats` (from ddpm3d_conv_stats_rows) */
-    float* stats;           /* [N][stats_rows][Cout][2] or NULL                      */
+    float* stats;           /* [N][Cout][stats_rows][2] (channel-major) or NULL      */
     /* scratch for split-K partial sums (low-resolution levels, where the voxel
      * tiles alone cannot fill 256 CUs); >= ddpm3d_conv_workspace_bytes(...) bytes,
      * may be shared by all convs of a stream, NULL when that query returns 0 */
@@ -149,8 +149,8 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* desc, void* stream);
  * GroupNorm32 statistics -> affine coefficients (nn.py:93-100: 32 groups,
  * eps 1e-5, affine gamma/beta), optionally composed with FiLM
  * h*(1+scale)+shift (unet.py:248-252).  The normalised tensor is the virtual
- * concat of up to two tensors with partial sums stats0 [N][rows0][C0][2] and
- * stats1 [N][rows1][C1][2]; `count` = voxels per channel.
+ * concat of up to two tensors with partial sums stats0 [N][C0][rows0][2] and
+ * stats1 [N][C1][rows1][2]; `count` = voxels per channel.
  *   A[n][c] = rstd*gamma[c]*(1+scale[n][c]);
  *   B[n][c] = (beta[c]-mean*rstd*gamma[c])*(1+scale[n][c]) + shift[n][c]
  * film = [N][film_stride] rows holding scale at [film_off, +C) and shift at
@@ -164,7 +164,7 @@ int ddpm3d_gn_finalize(const float* stats0, int C0, int rows0,
                        float* aff_a, float* aff_b, void* stream);
 
 /* partial sums of an NDHWC tensor that no conv epilogue produced;
- * stats [N][rows][C][2] with rows = ddpm3d_gn_stats_rows(voxels) */
+ * stats [N][C][rows][2] with rows = ddpm3d_gn_stats_rows(voxels) */
 int ddpm3d_gn_stats_rows(int voxels);
 int ddpm3d_gn_stats(const float* x, int N, int voxels, int C, float* stats, void* stream);
 

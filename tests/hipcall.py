@@ -66,7 +66,7 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
         d.workspace, d.workspace_bytes = H.ptr(ws), need
     stats = None
     if want_stats and out_layout == H.OUT_NDHWC:
-        stats = torch.full((N, rows, co, 2), float("nan"), dtype=torch.float32, device=dev)
+        stats = torch.full((N, co, rows, 2), float("nan"), dtype=torch.float32, device=dev)
         d.stats, d.stats_rows = H.ptr(stats), rows
     H.check(lib.ddpm3d_conv3d(C.byref(d), H.stream()))
     torch.cuda.synchronize()
@@ -78,12 +78,12 @@ def gn_finalize(stats_list, count, gamma, beta, film=None, film_stride=0, film_o
     s0 = stats_list[0]
     s1 = stats_list[1] if len(stats_list) > 1 else None
     N = s0.shape[0]
-    Cn = s0.shape[2] + (s1.shape[2] if s1 is not None else 0)
+    Cn = s0.shape[1] + (s1.shape[1] if s1 is not None else 0)
     A = torch.empty(N, Cn, dtype=torch.float32, device=s0.device)
     B = torch.empty(N, Cn, dtype=torch.float32, device=s0.device)
-    H.check(lib.ddpm3d_gn_finalize(H.ptr(s0), s0.shape[2], s0.shape[1],
-                                   H.ptr(s1), s1.shape[2] if s1 is not None else 0,
-                                   s1.shape[1] if s1 is not None else 0,
+    H.check(lib.ddpm3d_gn_finalize(H.ptr(s0), s0.shape[1], s0.shape[2],
+                                   H.ptr(s1), s1.shape[1] if s1 is not None else 0,
+                                   s1.shape[2] if s1 is not None else 0,
                                    N, groups, float(count), 1e-5, H.ptr(gamma), H.ptr(beta),
                                    H.ptr(film), film_stride, film_off, H.ptr(A), H.ptr(B), H.stream()))
     torch.cuda.synchronize()
@@ -96,7 +96,7 @@ def gn_stats(x_ndhwc):
     Cn = x_ndhwc.shape[-1]
     vox = x_ndhwc[0].numel() // Cn
     rows = lib.ddpm3d_gn_stats_rows(vox)
-    st = torch.full((N, rows, Cn, 2), float("nan"), dtype=torch.float32, device=x_ndhwc.device)
+    st = torch.full((N, Cn, rows, 2), float("nan"), dtype=torch.float32, device=x_ndhwc.device)
     H.check(lib.ddpm3d_gn_stats(H.ptr(x_ndhwc), N, vox, Cn, H.ptr(st), H.stream()))
     torch.cuda.synchronize()
     return st

@@ -36,7 +36,7 @@ def ref_stats(y_ncdhw):
 
 
 def check_stats(stats, y_ncdhw):
-    s = stats.double().sum(dim=1).cpu()  # [N][C][2]
+    s = stats.double().sum(dim=2).cpu()  # [N][C][rows][2] -> [N][C][2]
     r1, r2 = ref_stats(y_ncdhw)
     assert torch.allclose(s[..., 0], r1, rtol=1e-4, atol=1e-2)
     assert torch.allclose(s[..., 1], r2, rtol=1e-4, atol=1e-2)
