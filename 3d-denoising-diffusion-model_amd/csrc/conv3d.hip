@@ -393,16 +393,30 @@ hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st) {
 hipError_t ddpm3d_launch_conv_p0(const ConvK& k, const ConvCfg& c, hipStream_t st);
 hipError_t ddpm3d_launch_conv_p1(const ConvK& k, const ConvCfg& c, hipStream_t st);
 hipError_t ddpm3d_launch_conv_p2(const ConvK& k, const ConvCfg& c, hipStream_t st);
+hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t st);
 
 hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) {
     switch (c.PREC) {
         case 0: return ddpm3d_launch_conv_p0(k, c, st);
         case 1: return ddpm3d_launch_conv_p1(k, c, st);
         case 2: return ddpm3d_launch_conv_p2(k, c, st);
+        case 3: return ddpm3d_launch_conv_wz(k, c, st);
     }
     return hipErrorInvalidValue;
 }
 #endif  // DDPM3D_PREC_ONLY == 0
+
+#if DDPM3D_PREC_ONLY == 1
+// Winograd-D form of the f16x3 3x3x3 conv (eligibility is checked by the C ABI)
+#include "conv3d_wz.h"
+hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t st) {
+    const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
+    const int gy = k.CoutPad / 128;
+    constexpr size_t lds = (size_t)4 * LdsGeom<8, 10, 10>::RZ * 16;
+    hipLaunchKernelGGL(conv3d_wz_kernel<0>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+    return hipGetLastError();
+}
+#endif
 
 // ---------------------------------------------------------------- dispatch
 template <int PREC, int PIPE, int KS, int WN, int MT, int TXL, int TYL>

@@ -72,9 +72,76 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, const float* __restr
     }
 }
 
+// Winograd F(2,3) along depth (conv3d_wz.h): weight transform at pack time.  For every
+// (cout, ci, dy, dx): U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2 with g_k the
+// weight at dz = k; 36 "taps" ordered (j, dy, dx).
+__device__ __forceinline__ float wz_weight(const float* __restrict__ w, size_t co_ci, int j, int dydx) {
+    const float g0 = w[co_ci * 27 + dydx], g1 = w[co_ci * 27 + 9 + dydx], g2 = w[co_ci * 27 + 18 + dydx];
+    if (j == 0) return g0;
+    if (j == 3) return g2;
+    return j == 1 ? 0.5f * ((g0 + g2) + g1) : 0.5f * ((g0 + g2) - g1);
+}
+
+__global__ __launch_bounds__(256) void pack_wz_scale_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                            float* __restrict__ wscale) {
+    const int co = blockIdx.x;
+    float m = 0.0f;
+    if (co < Cout)
+        for (int i = threadIdx.x; i < Cin * 36; i += 256) {
+            const int ci = i / 36, tap = i % 36;
+            m = fmaxf(m, fabsf(wz_weight(w, (size_t)co * Cin + ci, tap / 9, tap % 9)));
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float s = 1.0f;
+        if (m > 0.0f && m < 3.0e38f) s = exp2f(floorf(log2f(DDPM3D_X3_W_TARGET / m)));
+        s = fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
+        wscale[co] = 1.0f / (DDPM3D_X3_ACT_SCALE * s);
+    }
+}
+
+__global__ void pack_wz_kernel(const float* __restrict__ w, const float* __restrict__ wscale, int Cout, int Cin,
+                               int CoutPad, int CinPad, _Float16* __restrict__ out) {
+    const size_t total = (size_t)36 * CinPad * CoutPad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int jj = (int)(i & 15);
+        size_t r = i >> 4;
+        const int co = (int)(r % CoutPad); r /= CoutPad;
+        const int cb = (int)(r % (CinPad / 16));
+        const int tap = (int)(r / (CinPad / 16));
+        const int ci = cb * 16 + jj;
+        float v = 0.0f;
+        if (co < Cout && ci < Cin)
+            v = wz_weight(w, (size_t)co * Cin + ci, tap / 9, tap % 9) * (1.0f / (DDPM3D_X3_ACT_SCALE * wscale[co]));
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const size_t base = (((size_t)tap * (CinPad / 16) + cb) * 2) * CoutPad * 16;
+        out[base + (size_t)co * 16 + jj] = hi;
+        out[base + (size_t)CoutPad * 16 + (size_t)co * 16 + jj] = lo;
+    }
+}
+
 hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, int prec, void* out, hipStream_t st) {
-    const int taps = ks * ks * ks;
     const int CoutPad = ddpm3d_cout_pad(Cout), CinPad = ddpm3d_cin_pad(Cin);
+    if (prec == DDPM3D_PREC_F16X3_WZ) {   // [f16 image of 36 transformed taps][CoutPad fp32 wscale]
+        const size_t total = (size_t)36 * CinPad * CoutPad;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        float* wscale = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + total * 4);
+        hipLaunchKernelGGL(pack_wz_scale_kernel, dim3(CoutPad), dim3(256), 0, st, w, Cout, Cin, wscale);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(pack_wz_kernel, dim3(blocks), dim3(256), 0, st, w, wscale, Cout, Cin, CoutPad, CinPad,
+                           (_Float16*)out);
+        return hipGetLastError();
+    }
+    const int taps = ks * ks * ks;
     const size_t total = (size_t)taps * CinPad * CoutPad;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;

@@ -20,6 +20,7 @@ for every step of the schedule.
 
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -39,10 +40,11 @@ class Act:
 
 
 class PackedConv:
-    __slots__ = ("w", "b", "Cout", "Cin", "k", "precision")
+    __slots__ = ("w", "b", "Cout", "Cin", "k", "precision", "wz")
 
     def __init__(self, weight, bias, precision, stream):
         lib = H.load()
+        self.wz = None   # optional Winograd-along-depth packing of the same layer
         Cout, Cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
         n = lib.ddpm3d_packed_weight_bytes(Cout, Cin, k, precision)
         if n == 0:
@@ -73,12 +75,18 @@ class UNetEngine:
         self.plans = {}
         st = H.stream()
         self.conv = {}
+        self.winograd = os.environ.get("DDPM3D_WINOGRAD", "1") != "0"
         for name, t in params.items():
             if name.endswith(".weight") and t.dim() >= 3:
                 base = name[:-len(".weight")]
                 w = t if t.dim() == 5 else t.reshape(t.shape[0], t.shape[1], 1, 1, 1)
                 prec = H.PRECISIONS[precision]
                 self.conv[base] = PackedConv(w, params[base + ".bias"], prec, st)
+                # f16x3: the big 3x3x3 layers also get the Winograd-along-depth form (1.5x fewer
+                # MFMAs); conv_step picks it per call where the shape / input mode allow
+                if (prec == H.PREC_F16X3 and self.winograd and w.shape[2] == 3 and w.shape[0] % 128 == 0
+                        and w.shape[1] % 16 == 0):
+                    self.conv[base].wz = PackedConv(w, params[base + ".bias"], H.PREC_F16X3_WZ, st)
         # fuse every ResBlock's emb_layers Linear into one [total, ted] matrix
         ws, bs, self.film_off = [], [], {}
         off = 0
@@ -261,8 +269,13 @@ class _Plan:
         if aff is not None:
             d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
         d.act = act
-        d.precision = pc.precision
-        d.w_packed, d.bias = H.ptr(pc.w), H.ptr(pc.b)
+        if (pc.wz is not None and not planar and in_mode in (H.IN_SAME, H.IN_UP)
+                and d.H >= 8 and d.W >= 8):
+            pc_use = pc.wz       # Winograd-D form: same layer, same arithmetic, 2/3 of the MFMAs
+        else:
+            pc_use = pc
+        d.precision = pc_use.precision
+        d.w_packed, d.bias = H.ptr(pc_use.w), H.ptr(pc.b)
         d.bias_stride_n = 0  # per-sample bias rows are patched in run()
         d.res_mode = res_mode
         d.res = H.ptr(res.buf) if res is not None else 0
@@ -276,7 +289,7 @@ class _Plan:
         wn = 4 if pc.Cout > 64 else (2 if pc.Cout > 32 else 1)
         tile = 8 if (d.H >= 8 and d.W >= 8) else 4
         flops = 2.0 * N * d.D * d.H * d.W * pc.Cout * d.Cin * pc.k ** 3
-        self.conv_meta[len(self.steps)] = ("conv3d_p%d_k%d_wn%d_t%d" % (pc.precision, pc.k, wn, tile), flops)
+        self.conv_meta[len(self.steps)] = ("conv3d_p%d_k%d_wn%d_t%d" % (pc_use.precision, pc.k, wn, tile), flops)
         self.steps.append((self.eng.lib.ddpm3d_conv3d, [C.byref(d), 0]))
         return d
 

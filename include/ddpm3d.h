@@ -131,7 +131,17 @@ const char* ddpm3d_last_error(void);
  *                      fp32 accumulate: the analogue of the reference's --use_fp16 torso
  *                      (unet.py:999-1005, fp16_util.py:15-22); ~2^-11 operand error, judged
  *                      by PSNR, not by the 1e-3 parity bar.  Same packed image as F16X3. */
-enum { DDPM3D_PREC_F32 = 0, DDPM3D_PREC_F16X3 = 1, DDPM3D_PREC_F16 = 2 };
+enum {
+    DDPM3D_PREC_F32 = 0,
+    DDPM3D_PREC_F16X3 = 1,
+    DDPM3D_PREC_F16 = 2,
+    /* F16X3 arithmetic on the Winograd F(2,3)-along-depth form of a 3x3x3 conv: 4 products
+     * per two outputs instead of 6 (the weights are transformed at pack time, the inputs
+     * while they are staged, the outputs in the epilogue).  Available for ksize 3, Cout a
+     * multiple of 128, H and W >= 8, input modes SAME / UP; other calls return DDPM3D_ENOSUP
+     * and must use the F16X3 packing of the same weights. */
+    DDPM3D_PREC_F16X3_WZ = 3
+};
 
 /* bytes of the packed form of an (Cout, Cin, k, k, k) weight for a precision mode */
 size_t ddpm3d_packed_weight_bytes(int Cout, int Cin, int ksize, int precision);

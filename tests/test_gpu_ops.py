@@ -93,7 +93,7 @@ def test_conv3d_f16x3_accuracy_is_fp32_grade(hc):
     b = rnd(128, seed=13)
     ref = F.conv3d(x.double(), w.double(), b.double(), padding=1)
     errs = []
-    for precision in (0, 1):
+    for precision in (0, 1, 3):
         out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (4, 16, 16), precision=precision)
         got = hc.to_ncdhw(out.cpu()).double()
         # per-output-channel relative error (small channels must not drown in the big ones)
@@ -101,6 +101,58 @@ def test_conv3d_f16x3_accuracy_is_fp32_grade(hc):
         errs.append(float(e))
     assert errs[0] < 2e-6 and errs[1] < 2e-6, errs
     assert errs[1] < 2 * errs[0] + 2e-7, errs
+    # Winograd-D form: the transforms add a few roundings (F(2,3) is the benign Winograd size)
+    assert errs[2] < 4e-6 and errs[2] < 4 * errs[0] + 4e-7, errs
+
+
+@pytest.mark.parametrize("N,D,Hh,W,ci,co", [
+    (1, 4, 16, 16, 48, 128),     # even D
+    (2, 5, 8, 24, 32, 256),      # odd D (last z-pair half valid), batch 2, two cout blocks
+    (1, 1, 9, 12, 16, 128),      # D = 1, ragged H / W
+    (1, 64, 8, 8, 256, 384),     # the published net's 8x8 level: split-K + reduce kernel
+])
+def test_conv3d_winograd_depth_form(hc, N, D, Hh, W, ci, co):
+    """precision 3: f16x3 arithmetic on the Winograd F(2,3)-along-depth form (weights transformed
+    at pack time, inputs while staged, outputs in the epilogue).  Same tolerance as the direct form."""
+    x = rnd(N, ci, D, Hh, W, seed=1)
+    w = rnd(co, ci, 3, 3, 3, seed=2, scale=0.05)
+    b = rnd(co, seed=3)
+    ref = F.conv3d(x, w, b, padding=1)
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (D, Hh, W), precision=3)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)
+
+
+def test_conv3d_winograd_depth_exact_and_fused_paths(hc):
+    """Integer data stays exact through the transforms (halves of small integers are exact); the
+    GroupNorm+SiLU prologue, nearest-upsampled input / residual and concat work in this form too."""
+    import guided_diffusion._hip as H
+    g = np.random.default_rng(5)
+    x = torch.from_numpy(g.integers(-3, 4, (1, 16, 5, 9, 10)).astype(np.float32))
+    w = torch.from_numpy((2 * g.integers(-2, 3, (128, 16, 3, 3, 3))).astype(np.float32))
+    b = torch.from_numpy(g.integers(-5, 6, (128,)).astype(np.float32))
+    out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (5, 9, 10), precision=3)
+    assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(x, w, b, padding=1))
+    # up-sampled block paths with a virtual concat of two sources
+    xa, xb = rnd(1, 32, 3, 4, 6, seed=1), rnd(1, 32, 3, 4, 6, seed=2)
+    xc = torch.cat([xa, xb], 1)
+    gamma, beta = 1 + 0.1 * rnd(64, seed=3), 0.1 * rnd(64, seed=4)
+    w2 = rnd(128, 64, 3, 3, 3, seed=6, scale=0.05)
+    b2 = rnd(128, seed=7)
+    r = rnd(1, 128, 3, 4, 6, seed=8)
+    up = lambda t: F.interpolate(t, (t.shape[2], t.shape[3] * 2, t.shape[4] * 2), mode="nearest")
+    ref = F.conv3d(up(F.silu(F.group_norm(xc, 32, gamma, beta, 1e-5))), w2, b2, padding=1) + up(r)
+    A, B = _gn_affine(hc, [xa, xb], gamma, beta)
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(xa).cuda(), hc.to_ndhwc(xb).cuda()], w2.cuda(), b2.cuda(), (3, 8, 12),
+                              in_mode=H.IN_UP, aff=(A, B), act=H.ACT_SILU, res=hc.to_ndhwc(r).cuda(),
+                              res_mode=H.RES_UP, precision=3)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)
+    # shapes / modes the form does not cover are refused, not silently mis-computed
+    lib = H.load()
+    assert lib.ddpm3d_packed_weight_bytes(96, 32, 3, 3) == 0
+    with pytest.raises(RuntimeError, match="Winograd"):
+        hc.conv3d([hc.to_ndhwc(rnd(1, 16, 4, 4, 4)).cuda()], w.cuda(), b.cuda(), (4, 4, 4), precision=3)
 
 
 def test_conv3d_f16_mode_is_half_precision_grade(hc):
