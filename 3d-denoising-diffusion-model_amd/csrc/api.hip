@@ -132,6 +132,9 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         const size_t wb = ddpm3d_packed_bytes(d->Cout, d->Cin, d->ksize, d->precision);
         if (b0 >= 0xFFFFFFF0LL || b1 >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0ULL)
             return fail(DDPM3D_EINVAL, "conv3d: a source tensor or the weights exceed 4 GiB; split the batch");
+        // the epilogue addresses one SAMPLE of the output (or residual) with 32-bit offsets
+        if ((long long)d->D * d->H * d->W * d->Cout * 4 >= 0xFFFFFFF0LL)
+            return fail(DDPM3D_EINVAL, "conv3d: one output sample exceeds 4 GiB; tile the volume");
         k.src0_bytes = (unsigned)b0; k.src1_bytes = (unsigned)b1; k.w_bytes = (unsigned)wb;
     }
     if (c.PREC != DDPM3D_PREC_F32)  // output scales sit behind the f16 image

@@ -409,11 +409,35 @@ hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) 
 #if DDPM3D_PREC_ONLY == 1
 // Winograd-D form of the f16x3 3x3x3 conv (eligibility is checked by the C ABI)
 #include "conv3d_wz.h"
+#include "conv3d_wz2.h"
 hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t st) {
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     const int gy = k.CoutPad / 128;
     constexpr size_t lds = (size_t)4 * LdsGeom<8, 10, 10>::RZ * 16;
-    hipLaunchKernelGGL(conv3d_wz_kernel<0>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+    // Experiment, opt-in: 8x8x4-voxel tiles, one wave per SIMD (conv3d_wz2.h).  DDPM3D_WZ2=1
+    // always (when D % 4 == 0), -1 for long reductions only (>= 16 chunks per workgroup, which
+    // amortise a lone workgroup's un-overlapped prologue and epilogue).  It ties the default
+    // kernel within 1-2 % (r01), so the default stays the simpler one.
+    static const int wz2 = [] { const char* e = getenv("DDPM3D_WZ2"); return e ? atoi(e) : 0; }();
+    if (k.D % 4 == 0 && (wz2 > 0 || (wz2 < 0 && k.chunks_per_split >= 16))) {
+        static const hipError_t attr =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wz2_kernel<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds));
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(conv3d_wz2_kernel<4>, dim3(gx / 2, gy, k.ksplit), dim3(256), 4 * lds, st, k);
+        return hipGetLastError();
+    }
+    // DDPM3D_WZ_DB=1 selects the double-buffered variant (one barrier per chunk, staging spread
+    // over the taps): 3-5 % slower than the single-image kernel with two workgroups per CU (r01)
+    static const bool db = [] { const char* e = getenv("DDPM3D_WZ_DB"); return e && atoi(e) != 0; }();
+    if (db) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wz_kernel<1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
+        if (attr != hipSuccess) return attr;
+        hipLaunchKernelGGL(conv3d_wz_kernel<1>, dim3(gx, gy, k.ksplit), dim3(256), 2 * lds, st, k);
+    } else {
+        hipLaunchKernelGGL(conv3d_wz_kernel<0>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+    }
     return hipGetLastError();
 }
 #endif

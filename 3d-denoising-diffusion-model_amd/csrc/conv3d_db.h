@@ -37,6 +37,71 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
     const size_t DHW = (size_t)p.D * p.H * p.W;
     // PREC 1/2: undo the operand scaling (exact: a power of two per cout)
     const float oscale = (PREC != 0 && cvalid) ? p.wscale[cout] : 1.0f;
+
+    // Fast path -- every launch of the network except ragged edge tiles, the NCDHW output conv
+    // and the up/down-sampling skip sums: the tile lies inside the volume, so element (t, reg)
+    // of a lane sits at  lane base (cout, half) + a WAVE-UNIFORM offset.  Stores (and the
+    // same-shaped residual loads) are buffer instructions with that offset in an SGPR: no
+    // per-element index arithmetic, bounds test or 64-bit address.  The general path below
+    // costs ~200 instructions per element, which for a 128-cin layer was a third of the
+    // kernel.  Same values in the same order, so both paths agree bit for bit.
+    {
+        constexpr int TZ = WM * MT * 32 / (TX * TY);
+        const bool split = p.ksplit > 1;
+        const bool full = z0 + TZ <= p.D && y0 + TY <= p.H && x0 + TX <= p.W;
+        if (full && p.out_layout == DDPM3D_OUT_NDHWC &&
+            (split || p.res_mode == DDPM3D_RES_NONE || p.res_mode == DDPM3D_RES_SAME)) {
+            const size_t samp = DHW * p.Cout;                       // elements per sample (< 2^30, C ABI guard)
+            const unsigned cstride = (unsigned)p.Cout * 4;          // bytes per voxel
+            float* dst = split ? p.partial + ((size_t)blockIdx.z * p.N + n) * samp : p.out + (size_t)n * samp;
+            const __amdgpu_buffer_rsrc_t drsrc = make_rsrc(dst, (unsigned)(samp * 4));
+            const bool resid = !split && p.res_mode == DDPM3D_RES_SAME;
+            const __amdgpu_buffer_rsrc_t rrsrc = make_rsrc(resid ? p.res + (size_t)n * samp : dst, (unsigned)(samp * 4));
+            // the lane's half adds 4 to the MFMA row: 4 voxels in x (8-wide tile) or one row in y (4-wide)
+            const unsigned hx = (4 * half) & (TX - 1), hy = ((4 * half) >> TXL) & (TY - 1);
+            const unsigned vbase = (((unsigned)z0 * p.H + y0 + hy) * p.W + x0 + hx) * cstride + (unsigned)cout * 4;
+            const unsigned voff = cvalid ? vbase : DDPM3D_OOB_OFFSET;   // out-of-range lanes: loads 0, stores dropped
+            const float bias = (!split && cvalid) ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                unsigned soff[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
+                    const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
+                    soff[reg] = (unsigned)((tz * p.H + ty) * p.W + tx) * cstride;
+                }
+                float r[16];
+                if (resid) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        r[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff, soff[reg], 0));
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    float val = PREC != 0 ? acc[t][reg] * oscale : acc[t][reg];
+                    if (!split) {
+                        val += bias;
+                        if (resid) val += r[reg];
+                        s1 += val;
+                        s2 = fmaf(val, val, s2);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), drsrc, voff, soff[reg], 0);
+                }
+            }
+            if (!split && p.stats != nullptr) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (half == 0 && cvalid) {
+                    const size_t row = (size_t)tile_in_n * WM + wm;
+                    *reinterpret_cast<float2*>(p.stats + (((size_t)n * p.Cout + cout) * p.stats_rows + row) * 2) =
+                        make_float2(s1, s2);
+                }
+            }
+            return;
+        }
+    }
     if (p.ksplit > 1) {
         // split-K: raw partial sums to this split's slab; bias / residual / statistics
         // are applied by the reduce kernel once all splits are in

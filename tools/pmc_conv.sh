@@ -31,10 +31,10 @@ for t in "abcd":
         continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(cc[0])):
-        if "conv3d_kernel" in r["Kernel_Name"]:
+        if "conv3d_" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     dur = [ (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt[0]))
-            if "conv3d_kernel" in r["Kernel_Name"] ] if kt else []
+            if "conv3d_" in r["Kernel_Name"] ] if kt else []
     print(f"pass {t}: kernel us (last) = {dur[-1] if dur else None}")
     for k, v in sorted(acc.items()):
         print(f"   {k:32s} {v[-1]:.4g}")
