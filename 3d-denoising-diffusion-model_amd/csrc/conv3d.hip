@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5;
 
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const WgId wg = wg_id(p);
+    int tile = wg.tile;
     const int tx_i = tile % p.tilesX; tile /= p.tilesX;
     const int ty_i = tile % p.tilesY; tile /= p.tilesY;
     const int tz_i = tile % p.tilesZ; tile /= p.tilesZ;
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
         arow[t] = (tz * RZ + ty * RY + tx * VS + half) * 16;
     }
 
-    const int cout = blockIdx.y * (32 * WN) + wn * 32 + (lane & 31);
-    const bool wave_active = (blockIdx.y * (32 * WN) + wn * 32) < p.CoutPad;
+    const int cout = wg.cy * (32 * WN) + wn * 32 + (lane & 31);
+    const bool wave_active = (wg.cy * (32 * WN) + wn * 32) < p.CoutPad;
     const int cout_ld = wave_active ? cout : 0;
     // Weight stream in 16-byte units.
     //   PREC 0: [tap][ci/8][CoutPad][8 f32]            -> 2 units per (8-ci block, cout)
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
 
     const int nchunks = p.CinPad / CK;
     // split-K: blockIdx.z owns a contiguous range of the Cin chunks
-    const int chunk_begin = blockIdx.z * p.chunks_per_split;
+    const int chunk_begin = wg.split * p.chunks_per_split;
     const int chunk_end = min(nchunks, chunk_begin + p.chunks_per_split);
 
     // Software pipeline of the staging (IN_SAME / IN_UP, one 16-byte load per item): the
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
     if (!wave_active) return;
 
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<PREC, WM, MT, TXL, TYL>(p, acc, n, z0, y0, x0, tile_in_n, wm, cout, half);
+    conv_epilogue<PREC, WM, MT, TXL, TYL>(p, acc, n, z0, y0, x0, tile_in_n, wm, cout, half, wg.split);
 }
 
 // This file is compiled once per arithmetic mode (-DDDPM3D_PREC_ONLY=0|1|2, see the
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) 
     const size_t DHW = (size_t)p.D * p.H * p.W;
     const int rows = p.stats_rows;
     const int n = blockIdx.x / rows, r = blockIdx.x % rows;
-    const size_t v0 = (size_t)r * DDPM3D_REDUCE_VOX;
-    const size_t v1 = min(v0 + (size_t)DDPM3D_REDUCE_VOX, DHW);
+    const size_t v0 = (size_t)r * p.reduce_vox;
+    const size_t v1 = min(v0 + (size_t)p.reduce_vox, DHW);
     const size_t slab_stride = (size_t)p.N * DHW * p.Cout;
     for (int cout = threadIdx.x; cout < p.Cout; cout += 256) {
         const float bias = p.bias[(size_t)n * p.bias_stride_n + cout];
@@ -321,32 +322,43 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) 
 }
 
 // Vectorised form for Cout % 4 == 0 and NDHWC output (every split conv of the network):
-// thread = (voxel lane vl = tid/64, channel quad cq = tid%64); each thread sums the S slabs
-// for 4 voxels x 4 channels with 16-byte loads (4 independent chains per pass instead of one
-// 16-voxel serial chain), then the 4 voxel lanes are folded through LDS for the statistics row.
+// workgroup = RV voxels (one statistics row) x 64 channel quads (blockIdx.y); thread = (voxel
+// lane vl = tid/64, channel quad cq = tid%64) sums the S slabs for RV/4 voxels x 4 channels
+// with 16-byte loads, four slabs in flight (added in slab order, like the scalar kernel),
+// then the 4 voxel lanes are folded through LDS for the statistics row.  RV shrinks with
+// the level (ddpm3d_reduce_vox) so that the 64x4x4 level still launches 512 workgroups.
+template <int RV>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK p) {
     const size_t DHW = (size_t)p.D * p.H * p.W;
     const int rows = p.stats_rows;
     const int n = blockIdx.x / rows, r = blockIdx.x % rows;
-    const size_t v0 = (size_t)r * DDPM3D_REDUCE_VOX;
+    const size_t v0 = (size_t)r * RV;
     const size_t slab_stride = (size_t)p.N * DHW * p.Cout;
     const int quads = p.Cout / 4;
     const int cq = threadIdx.x & 63, vl = threadIdx.x >> 6;
     __shared__ float red[2][4][64 * 4];
-    for (int q0 = 0; q0 < quads; q0 += 64) {
-        const int q = q0 + cq;
+    {
+        const int q = blockIdx.y * 64 + cq;
         const bool qok = q < quads;
         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         if (qok) {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + (size_t)n * p.bias_stride_n + q * 4);
 #pragma unroll
-            for (int i = 0; i < DDPM3D_REDUCE_VOX / 4; ++i) {
+            for (int i = 0; i < RV / 4; ++i) {
                 const size_t v = v0 + vl + 4 * i;
                 if (v < DHW) {
                     const size_t e = ((size_t)n * DHW + v) * p.Cout + q * 4;
                     f32x4 val = *reinterpret_cast<const f32x4*>(p.partial + e);
-                    for (int s = 1; s < p.ksplit; ++s)
-                        val += *reinterpret_cast<const f32x4*>(p.partial + e + s * slab_stride);
+                    int s = 1;
+                    for (; s + 3 < p.ksplit; s += 4) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(p.partial + e + (size_t)s * slab_stride);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(p.partial + e + (size_t)(s + 1) * slab_stride);
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(p.partial + e + (size_t)(s + 2) * slab_stride);
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(p.partial + e + (size_t)(s + 3) * slab_stride);
+                        val += a; val += b; val += c; val += d;
+                    }
+                    for (; s < p.ksplit; ++s)
+                        val += *reinterpret_cast<const f32x4*>(p.partial + e + (size_t)s * slab_stride);
                     val += bias;
                     if (p.res_mode != DDPM3D_RES_NONE) {
                         const int x = (int)(v % p.W), y = (int)((v / p.W) % p.H), z = (int)(v / ((size_t)p.W * p.H));
@@ -383,9 +395,15 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK 
 }
 
 hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st) {
-    if (k.Cout % 4 == 0 && k.out_layout == DDPM3D_OUT_NDHWC)
-        hipLaunchKernelGGL(conv_splitk_reduce_v4_kernel, dim3(k.N * k.stats_rows), dim3(256), 0, st, k);
-    else
+    if (k.Cout % 4 == 0 && k.out_layout == DDPM3D_OUT_NDHWC) {
+        const dim3 grid(k.N * k.stats_rows, (k.Cout / 4 + 63) / 64);
+        switch (k.reduce_vox) {
+            case 4: hipLaunchKernelGGL(conv_splitk_reduce_v4_kernel<4>, grid, dim3(256), 0, st, k); break;
+            case 8: hipLaunchKernelGGL(conv_splitk_reduce_v4_kernel<8>, grid, dim3(256), 0, st, k); break;
+            case 16: hipLaunchKernelGGL(conv_splitk_reduce_v4_kernel<16>, grid, dim3(256), 0, st, k); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(k.N * k.stats_rows), dim3(256), 0, st, k);
     return hipGetLastError();
 }

@@ -31,7 +31,7 @@ struct LdsGeom {
 // row = (reg&3) + 8*(reg>>2) + 4*half.
 template <int PREC, int WM, int MT, int TXL, int TYL>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc)[MT], int n, int z0, int y0,
-                                              int x0, int tile_in_n, int wm, int cout, int half) {
+                                              int x0, int tile_in_n, int wm, int cout, int half, int ksplit_idx) {
     constexpr int TX = 1 << TXL, TY = 1 << TYL;
     const bool cvalid = cout < p.Cout;
     const size_t DHW = (size_t)p.D * p.H * p.W;
@@ -53,7 +53,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
             (split || p.res_mode == DDPM3D_RES_NONE || p.res_mode == DDPM3D_RES_SAME)) {
             const size_t samp = DHW * p.Cout;                       // elements per sample (< 2^30, C ABI guard)
             const unsigned cstride = (unsigned)p.Cout * 4;          // bytes per voxel
-            float* dst = split ? p.partial + ((size_t)blockIdx.z * p.N + n) * samp : p.out + (size_t)n * samp;
+            float* dst = split ? p.partial + ((size_t)ksplit_idx * p.N + n) * samp : p.out + (size_t)n * samp;
             const __amdgpu_buffer_rsrc_t drsrc = make_rsrc(dst, (unsigned)(samp * 4));
             const bool resid = !split && p.res_mode == DDPM3D_RES_SAME;
             const __amdgpu_buffer_rsrc_t rrsrc = make_rsrc(resid ? p.res + (size_t)n * samp : dst, (unsigned)(samp * 4));
@@ -105,7 +105,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
     if (p.ksplit > 1) {
         // split-K: raw partial sums to this split's slab; bias / residual / statistics
         // are applied by the reduce kernel once all splits are in
-        float* slab = p.partial + ((size_t)blockIdx.z * p.N + n) * DHW * p.Cout;
+        float* slab = p.partial + ((size_t)ksplit_idx * p.N + n) * DHW * p.Cout;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -343,5 +343,5 @@ __global__ __launch_bounds__(256, 2) void conv3d_db_kernel(const ConvK p) {
     }
 
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<PREC, 1, MT, TXL, TYL>(p, acc, n, z0, y0, x0, tile_in_n, 0, cout, half);
+    conv_epilogue<PREC, 1, MT, TXL, TYL>(p, acc, n, z0, y0, x0, tile_in_n, 0, cout, half, blockIdx.z);
 }

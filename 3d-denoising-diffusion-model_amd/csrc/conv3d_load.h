@@ -14,7 +14,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //               whose operand representation error is of the same order.
 template <bool FAST>
 __device__ __forceinline__ float silu_f(float v) {
-    if (FAST) return __fdividef(v, 1.0f + __expf(-v));
+    // (not __fdividef: hipcc expands that to the full div_scale/div_fmas/div_fixup sequence,
+    // ~10 instructions -- it was a third of the staging VALU of the f16x3 kernels)
+    if (FAST) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     return v / (1.0f + expf(-v));
 }
 
@@ -146,6 +148,36 @@ __device__ __forceinline__ f32x4 halo_finish(const HaloSrc& h, f32x4 raw, bool i
     }
     return r;
 }
+
+// Which (tile, cout block, K split) a workgroup owns.  Workgroups go to the 8 XCDs round-robin
+// in linear-id order (x fastest), and each XCD has its own L2:
+//   - default (activations outweigh weights): consecutive TILES on one XCD (xcd_remap), so the
+//     halo planes two tiles share are fetched once per XCD;
+//   - p.wstat (weights outweigh activations, the low-resolution levels): (cout block, split)
+//     fastest, so one XCD keeps meeting the same 1/8 of the weight image.  Measured before
+//     (r01, 512->512 @ 64x4x4, split-K): 255 MB of fabric traffic per launch for 4 MB of
+//     activations -- eight private copies of the 28 MB weight image.
+struct WgId { int tile, cy, split; };
+__device__ __forceinline__ int xcd_remap(int bid, int nwg);
+__device__ __forceinline__ WgId wg_id(const ConvK& p) {
+    WgId w;
+    if (p.wstat) {
+        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int nyz = gridDim.y * gridDim.z;
+        const int yz = L % nyz;
+        w.tile = L / nyz;
+        w.cy = yz % gridDim.y;
+        w.split = yz / gridDim.y;
+    } else {
+        w.tile = xcd_remap(blockIdx.x, gridDim.x);
+        w.cy = blockIdx.y;
+        w.split = blockIdx.z;
+    }
+    return w;
+}
+
+// (Tried and dropped, r01: folding the x8 split scale into the affine and forming lo = s - hi
+// as one fma saves 60 of 440 staging instructions but measured 2 % SLOWER on the same box.)
 
 // XCD-aware tile order: consecutive tiles (which share halo planes) on one XCD's L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

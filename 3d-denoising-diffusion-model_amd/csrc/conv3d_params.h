@@ -32,6 +32,8 @@ struct ConvK {
     int in_mode, act, bias_stride_n, res_mode, out_layout, stats_rows;
     int tilesX, tilesY, tilesZ;
     int ksplit, chunks_per_split;
+    int wstat;  // weight-stationary workgroup -> XCD order (conv3d_load.h wg_id)
+    int reduce_vox;  // voxels per statistics row of the split-K reduce
 };
 
 struct ConvCfg {
@@ -43,6 +45,7 @@ struct ConvCfg {
     int S;         // split-K factor over the Cin chunks (1 = none)
     int tilesX, tilesY, tilesZ;
     int stats_rows;           // rows per sample the executing path writes
+    int reduce_vox;           // voxels per statistics row of the split-K reduce (16, 8 or 4)
     size_t workspace_bytes;   // slabs needed when S > 1
 };
 
@@ -102,8 +105,15 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
     }
     c.S = best;
     const long long vox = (long long)D * H * W;
+    // voxels per workgroup (= per statistics row) of the split-K reduce: 16, or fewer on the
+    // small levels so that the reduce still launches >= 1024 workgroups (r01: the 64x4x4
+    // level ran it on 64 workgroups, 23 us a launch, 6.6 % of the forward)
+    c.reduce_vox = DDPM3D_REDUCE_VOX;
+    while (c.reduce_vox > 4 &&
+           (long long)N * ((vox + c.reduce_vox - 1) / c.reduce_vox) * ((Cout / 4 + 63) / 64) < 1024)
+        c.reduce_vox /= 2;
     if (c.S > 1) {
-        c.stats_rows = (int)((vox + DDPM3D_REDUCE_VOX - 1) / DDPM3D_REDUCE_VOX);
+        c.stats_rows = (int)((vox + c.reduce_vox - 1) / c.reduce_vox);
         c.workspace_bytes = (size_t)c.S * N * vox * Cout * sizeof(float);
     } else {
         c.stats_rows = c.tilesZ * c.tilesY * c.tilesX * (4 / c.WN);

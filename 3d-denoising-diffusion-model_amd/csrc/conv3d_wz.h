@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
 
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const WgId wg = wg_id(p);
+    int tile = wg.tile;
     const int tx_i = tile % p.tilesX; tile /= p.tilesX;
     const int ty_i = tile % p.tilesY; tile /= p.tilesY;
     const int tz_i = tile % p.tilesZ; tile /= p.tilesZ;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         arow[t] = ((m >> TXL) * RY + (m & (TX - 1)) * VS + half) * 16;
     }
 
-    const int cout = blockIdx.y * 128 + wn * 32 + (lane & 31);
+    const int cout = wg.cy * 128 + wn * 32 + (lane & 31);
     const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.w_bytes);
     const unsigned wlane = ((unsigned)cout * 2 + half) * 16;
     const unsigned wpart = (unsigned)p.CoutPad * 32;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
             for (int i = 0; i < 16; ++i) acc[j][t][i] = 0.0f;
 
     const int nchunks = p.CinPad / CK;
-    const int chunk_begin = blockIdx.z * p.chunks_per_split;
+    const int chunk_begin = wg.split * p.chunks_per_split;
     const int chunk_end = min(nchunks, chunk_begin + p.chunks_per_split);
 
     const int q = tid % QPV;
@@ -256,5 +257,5 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         outv[2 + t] = acc[1][t] - acc[2][t] - acc[3][t];
     }
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<1, 1, 4, TXL, TYL>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half);
+    conv_epilogue<1, 1, 4, TXL, TYL>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split);
 }

@@ -277,6 +277,6 @@ __global__ __launch_bounds__(256, 1) void conv3d_wz2_kernel(const ConvK p) {
             outv[t] = acc[0][t][u] + acc[1][t][u] + acc[2][t][u];
             outv[2 + t] = acc[1][t][u] - acc[2][t][u] - acc[3][t][u];
         }
-        conv_epilogue<1, 2, 4, TXL, TYL>(p, outv, n, z0, y0, x0, tile_in_n, zp, cout0 + 32 * u, half);
+        conv_epilogue<1, 2, 4, TXL, TYL>(p, outv, n, z0, y0, x0, tile_in_n, zp, cout0 + 32 * u, half, blockIdx.z);
     }
 }

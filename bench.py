@@ -23,6 +23,7 @@ cpu_baseline : oracle/ (the CPU restatement pinned to the reference) timed on
 """
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -247,9 +248,24 @@ def main():
     if dom:
         tag, (cnt, fl, ms) = dom
         ach = fl / (ms * 1e-3) / 1e12
+        # HBM-side bytes per launch of the same kernel over the same launch mix: PMC counters
+        # cannot be read from inside this process, so they come from the committed rocprofv3
+        # pass over THIS workload (tools/pmc_bench.sh -> profiles/rNN_pmc_traffic.json);
+        # null for any other configuration.
+        traffic, traffic_src = None, None
+        sig = "%s|%d|%d|%s|%s" % (args.precision, S, B, args.arch, args.attention_resolutions)
+        here = os.path.dirname(os.path.abspath(__file__))
+        for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            with open(f) as fh:
+                tj = json.load(fh)
+            k = tj.get("kernels", {}).get(tag)
+            if tj.get("signature") == sig and k:
+                traffic, traffic_src = round(k["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(f)
+                break
         roof = {
             "bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
             "peak_basis": ARITH[args.precision][2],
             "launches_timed": cnt, "avg_launch_ms": round(ms / cnt, 4),
             "all_conv_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
