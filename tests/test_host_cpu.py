@@ -55,8 +55,11 @@ def test_library_exports_every_declared_symbol():
     # 64x32x32 level: 128-voxel tiles (2x8x8)
     assert lib.ddpm3d_conv_stats_rows(1, 64, 32, 32, 128, 128, 3) == 32 * 4 * 4
     assert lib.ddpm3d_conv_workspace_bytes(1, 64, 64, 64, 128, 128, 3) == 0
-    # 64x4x4 level: 8 voxel tiles -> split over Cin, rows of 16 voxels from the reduce kernel
-    assert lib.ddpm3d_conv_stats_rows(1, 64, 4, 4, 512, 512, 3) == 64
+    # 64x4x4 level: 8 voxel tiles -> split over Cin; the reduce kernel's rows shrink from 16 to 4
+    # voxels on this level so that it still launches >= 1024 workgroups (256 rows x 2 quad blocks)
+    assert lib.ddpm3d_conv_stats_rows(1, 64, 4, 4, 512, 512, 3) == 256
+    # eight samples of the same level: 8 x 64 rows x 2 quad blocks of 16 voxels already fill it
+    assert lib.ddpm3d_conv_stats_rows(8, 64, 4, 4, 512, 512, 3) == 64
     ws = lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 512, 512, 3)
     assert ws > 0 and ws % (1024 * 512 * 4) == 0
 
