@@ -84,6 +84,27 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
     const long long blocks = mtiles * ((ddpm3d_cout_pad(Cout) + 32 * c.WN - 1) / (32 * c.WN));
     const int nch = ddpm3d_cin_pad(Cin) / DDPM3D_CONV_CK;
     int best = 1;
+    if (ksize == 1 && c.WN == 4) {
+        // 1x1: a chunk is one tap, so a workgroup's time is latency per chunk (barrier + an
+        // exposed halo load, ~1 us) and the split pays when few workgroups each walk many
+        // chunks.  Units ~us: chunk 1, prologue + epilogue 3, the reduce launch 10.  Measured
+        // before (r01): 1024->512 @ 64x4x4 took 71 us on 32 workgroups x 64 chunks.
+        const char* force = getenv("DDPM3D_KSPLIT1");
+        if (force) {
+            best = atoi(force);
+            if (best < 1) best = 1;
+            if (best > nch) best = nch;
+        } else {
+            double best_cost = 1e300;
+            for (int s = 1; s <= 32 && s <= nch; ++s) {
+                const int cps = (nch + s - 1) / s;
+                if (s > 1 && cps < 4) break;
+                const long long per_cu = (blocks * s + 255) / 256;
+                const double cost = (double)per_cu * (cps + 3.0) + (s > 1 ? 10.0 : 0.0);
+                if (cost < best_cost * 0.9) { best_cost = cost; best = s; }
+            }
+        }
+    }
     if (ksize == 3 && c.WN == 4) {
         const char* force = getenv("DDPM3D_KSPLIT");
         if (force) {

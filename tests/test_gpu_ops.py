@@ -431,3 +431,27 @@ def test_sampler_update_kernels(hc, learn, xstart, clip):
             sig = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
             ref2 = x0 * torch.sqrt(abp) + torch.sqrt(1 - abp - sig ** 2) * eps + (0.0 if i == 0 else 1.0) * sig * z
             assert rel_err(got2["sample"].cpu().numpy(), ref2.numpy()) < 2e-6
+
+
+def test_conv3d_variants_agree_bitwise():
+    """The opt-in forms of the Winograd conv (double-buffered LDS, the 8x8x4-tile one-wave-per-SIMD
+    kernel) and both workgroup -> XCD orders claim the SAME arithmetic per output element as the
+    default kernel: outputs and GroupNorm partial sums must be bit-identical.  The switches are
+    read once per process, so each variant runs tests/variant_conv.py in its own process (one at a
+    time: the box allows few processes on the GPU)."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variant_conv.py")
+    variants = [{}, {"DDPM3D_WZ_DB": "1"}, {"DDPM3D_WZ2": "1"}, {"DDPM3D_WSTAT": "1"}, {"DDPM3D_WSTAT": "0"}]
+    outs = []
+    for v in variants:
+        env = {k: x for k, x in os.environ.items() if k not in ("DDPM3D_WZ_DB", "DDPM3D_WZ2", "DDPM3D_WSTAT")}
+        env.update(v)
+        r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, "variant %s failed:\n%s" % (v, r.stderr[-2000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("case")]
+        assert len(lines) == 3, r.stdout
+        outs.append(lines)
+    for v, o in zip(variants[1:], outs[1:]):
+        assert o == outs[0], "variant %s differs from the default kernel:\n%s\n%s" % (v, o, outs[0])
