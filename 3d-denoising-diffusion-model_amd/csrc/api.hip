@@ -206,6 +206,13 @@ int ddpm3d_ndhwc_to_ncdhw(const float* in, int N, int C, int voxels, float* out,
     return launched(ddpm3d_launch_transpose(in, N, voxels, C, out, (hipStream_t)stream), "ndhwc_to_ncdhw");
 }
 
+int ddpm3d_subsample_hw2(const float* in, int N, int D, int H, int W, int C, float* out, void* stream) {
+    if (!in || !out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1) || (C & 3) ||
+        !aligned16(in) || !aligned16(out))
+        return fail(DDPM3D_EINVAL, "subsample_hw2: needs even H, W, C %% 4 == 0 and 16-byte aligned tensors");
+    return launched(ddpm3d_launch_subsample_hw2(in, N, D, H, W, C, out, (hipStream_t)stream), "subsample_hw2");
+}
+
 int ddpm3d_attention(const float* qkv, int N, int T, int heads, int head_channels, float* out, void* stream) {
     if (!qkv || !out || N <= 0 || T <= 0 || heads <= 0) return fail(DDPM3D_EINVAL, "attention: bad arguments");
     if (head_channels != 32 && head_channels != 64 && head_channels != 128)

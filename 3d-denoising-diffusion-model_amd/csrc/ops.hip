@@ -401,6 +401,29 @@ hipError_t ddpm3d_launch_transpose(const float* in, int N, int R, int S, float* 
     return hipGetLastError();
 }
 
+// out[n][z][y][x][:] = in[n][z][2y][2x][:]  (NDHWC, C % 4 == 0): the even positions of a
+// stride-1 conv output = the stride-(1,2,2) conv of Downsample(use_conv=True), unet.py:129-133.
+__global__ __launch_bounds__(256) void subsample_hw2_kernel(const float4* __restrict__ in, int D, int H, int W,
+                                                            int C4, float4* __restrict__ out, size_t total) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t v = i / C4;
+        const int x = (int)(v % Wo); v /= Wo;
+        const int y = (int)(v % Ho); v /= Ho;   // v = n * D + z
+        out[i] = in[((v * H + 2 * y) * W + 2 * x) * C4 + c];
+    }
+}
+
+hipError_t ddpm3d_launch_subsample_hw2(const float* in, int N, int D, int H, int W, int C, float* out,
+                                       hipStream_t st) {
+    const size_t total = (size_t)N * D * (H / 2) * (W / 2) * (C / 4);
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(subsample_hw2_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(in), D, H, W, C / 4, reinterpret_cast<float4*>(out), total);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------- sampler update
 // The arithmetic order mirrors the reference's torch expressions one rounding
 // at a time, so contraction into FMAs is switched off here.

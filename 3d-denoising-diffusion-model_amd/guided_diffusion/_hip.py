@@ -23,7 +23,7 @@ F_LEARN_SIGMA, F_PREDICT_XSTART, F_CLIP = 1, 2, 4
 NCOEF = 8
 PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X3_WZ = 0, 1, 2, 3
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _fp = C.c_void_p
 
@@ -59,6 +59,7 @@ EXPORTS = {
     "ddpm3d_attention": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_ncdhw_to_ndhwc": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_ndhwc_to_ncdhw": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ddpm3d_subsample_hw2": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_p_sample_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ddpm3d_ddim_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float,
                                    _fp, _fp, _fp]),

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DDPM3D_ABI_VERSION 4
+#define DDPM3D_ABI_VERSION 5
 
 enum {
     DDPM3D_OK = 0,
@@ -202,6 +202,13 @@ int ddpm3d_attention(const float* qkv, int N, int T, int heads, int head_channel
 /* layout changes at the API edge */
 int ddpm3d_ncdhw_to_ndhwc(const float* in, int N, int C, int voxels, float* out, void* stream);
 int ddpm3d_ndhwc_to_ncdhw(const float* in, int N, int C, int voxels, float* out, void* stream);
+
+/* out[n][z][y][x][:] = in[n][z][2y][2x][:] on NDHWC tensors (even H, W; C % 4 == 0).
+ * Downsample(use_conv=True) (unet.py:129-133, `resblock_updown=False`): a 3x3x3 conv with
+ * stride (1,2,2), pad 1 is the stride-1 conv kept at the even (y, x) -- ddpm3d_conv3d at full
+ * resolution, this call, then ddpm3d_gn_stats for the next GroupNorm.  (Correct, not fast:
+ * 3/4 of that conv's work is discarded; the published model uses resblock_updown=True.) */
+int ddpm3d_subsample_hw2(const float* in, int N, int D, int H, int W, int C, float* out, void* stream);
 
 /*
  * One reverse-diffusion update for a batch (everything after the network call):

@@ -49,6 +49,8 @@ def inputs(shape):
     ("tiny_additive", dict(use_scale_shift_norm=False), (1, 1, 4, 16, 16), [5]),
     ("tiny_nosigma", dict(learn_sigma=False), (1, 1, 4, 16, 16), [5]),
     ("tiny_ls64", dict(large_size=64), (1, 1, 4, 16, 16), [5]),
+    # conv Downsample / Upsample between levels (unet.py:81-140), the factory's default flag
+    ("tiny_convresample", dict(resblock_updown=False), (1, 1, 4, 16, 16), [5]),
 ])
 def test_unet_forward_vs_reference_golden(golden, tag, over, shape, t):
     model, _ = build(dict(TINY, **over))

@@ -433,6 +433,31 @@ def test_sampler_update_kernels(hc, learn, xstart, clip):
             assert rel_err(got2["sample"].cpu().numpy(), ref2.numpy()) < 2e-6
 
 
+def test_strided_downsample_conv_as_conv_plus_subsample(hc):
+    """Downsample(use_conv=True) (unet.py:129-133): Conv3d(stride=(1,2,2), padding=1) equals the
+    stride-1 conv kept at the even (y, x) -- conv3d + ddpm3d_subsample_hw2, then ddpm3d_gn_stats."""
+    from guided_diffusion import _hip as H
+    lib = H.load()
+    N, D, Hh, W, ci, co = 2, 3, 12, 8, 32, 48
+    x = rnd(N, ci, D, Hh, W, seed=1)
+    w = rnd(co, ci, 3, 3, 3, seed=2, scale=0.05)
+    b = rnd(co, seed=3)
+    ref = F.conv3d(x, w, b, stride=(1, 2, 2), padding=1)
+    full, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (D, Hh, W), precision=1)
+    out = torch.full((N, D, Hh // 2, W // 2, co), float("nan"), dtype=torch.float32, device="cuda")
+    H.check(lib.ddpm3d_subsample_hw2(H.ptr(full), N, D, Hh, W, co, H.ptr(out), H.stream()))
+    vox = D * (Hh // 2) * (W // 2)
+    rows = lib.ddpm3d_gn_stats_rows(vox)
+    stats = torch.zeros(N, co, rows, 2, dtype=torch.float32, device="cuda")
+    H.check(lib.ddpm3d_gn_stats(H.ptr(out), N, vox, co, H.ptr(stats), H.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)
+    # odd extents / unaligned channel counts are refused, not mis-copied
+    assert lib.ddpm3d_subsample_hw2(H.ptr(full), N, D, Hh + 1, W, co, H.ptr(out), H.stream()) == -1  # DDPM3D_EINVAL
+    assert lib.ddpm3d_subsample_hw2(H.ptr(full), N, D, Hh, W, co + 2, H.ptr(out), H.stream()) == -1
+
+
 def test_conv3d_variants_agree_bitwise():
     """The opt-in forms of the Winograd conv (double-buffered LDS, the 8x8x4-tile one-wave-per-SIMD
     kernel) and both workgroup -> XCD orders claim the SAME arithmetic per output element as the
