@@ -121,6 +121,7 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     k.tilesZ = c.tilesZ; k.tilesY = c.tilesY; k.tilesX = c.tilesX;
     k.stats_rows = c.stats_rows;
     k.reduce_vox = c.reduce_vox;
+    k.ztiles = 1;
     k.ksplit = c.S;
     k.chunks_per_split = (k.CinPad / DDPM3D_CONV_CK + c.S - 1) / c.S;
     k.partial = (float*)d->workspace;

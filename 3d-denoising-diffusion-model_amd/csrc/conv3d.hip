@@ -428,6 +428,7 @@ hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) 
 // Winograd-D form of the f16x3 3x3x3 conv (eligibility is checked by the C ABI)
 #include "conv3d_wz.h"
 #include "conv3d_wz2.h"
+#include "conv3d_wzs.h"
 hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t st) {
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     const int gy = k.CoutPad / 128;
@@ -443,6 +444,39 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds));
         if (attr != hipSuccess) return attr;
         hipLaunchKernelGGL(conv3d_wz2_kernel<4>, dim3(gx / 2, gy, k.ksplit), dim3(256), 4 * lds, st, k);
+        return hipGetLastError();
+    }
+    // wave-specialised form (conv3d_wzs.h): 512 threads, waves 0-3 compute, 4-7 stage
+    // DDPM3D_WZS: 0 never, 1 / 2 always (A operands 1 / 2 taps ahead); unset: on the big grids,
+    // where it measured 2-3 % faster than the kernel below (r01: 0.463 / 0.874 vs 0.472 / 0.892 ms
+    // on 128->128 / 256->128 @ 64^3) -- on the small levels its lone workgroup per CU loses 3-7 %
+    static const int wzs_env = [] { const char* e = getenv("DDPM3D_WZS"); return e ? atoi(e) : -1; }();
+    const int wzs = wzs_env >= 0 ? wzs_env : ((long long)gx * gy * k.ksplit >= 2048 ? 1 : 0);
+    if (wzs != 0) {
+        const void* fn = wzs == 1 ? reinterpret_cast<const void*>(&conv3d_wzs_kernel<4, 1>)
+                                  : reinterpret_cast<const void*>(&conv3d_wzs_kernel<4, 2>);
+        static hipError_t attr1 = hipErrorUnknown, attr2 = hipErrorUnknown;
+        hipError_t& attr = wzs == 1 ? attr1 : attr2;
+        if (attr == hipErrorUnknown)
+            attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
+        if (attr != hipSuccess) return attr;
+        // z-pairs per workgroup: as many as still leave every CU two workgroups (balance)
+        static const int zt_force = [] { const char* e = getenv("DDPM3D_WZS_ZT"); return e ? atoi(e) : 0; }();
+        ConvK k2 = k;
+        k2.ztiles = 1;
+        if (zt_force > 0) {
+            k2.ztiles = zt_force < k.tilesZ ? zt_force : k.tilesZ;
+        } else {
+            while (k2.ztiles * 2 <= k.tilesZ && k2.ztiles < 8 &&
+                   (long long)gx * gy * k.ksplit / (k2.ztiles * 2) >= 512)
+                k2.ztiles *= 2;
+        }
+        const int zgroups = (k.tilesZ + k2.ztiles - 1) / k2.ztiles;
+        const int gxs = k.N * zgroups * k.tilesY * k.tilesX;
+        if (wzs == 1)
+            hipLaunchKernelGGL((conv3d_wzs_kernel<4, 1>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
+        else
+            hipLaunchKernelGGL((conv3d_wzs_kernel<4, 2>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
         return hipGetLastError();
     }
     // DDPM3D_WZ_DB=1 selects the double-buffered variant (one barrier per chunk, staging spread

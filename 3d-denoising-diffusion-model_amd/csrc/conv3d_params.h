@@ -34,6 +34,7 @@ struct ConvK {
     int ksplit, chunks_per_split;
     int wstat;  // weight-stationary workgroup -> XCD order (conv3d_load.h wg_id)
     int reduce_vox;  // voxels per statistics row of the split-K reduce
+    int ztiles;      // conv3d_wzs_kernel: consecutive z-pairs one workgroup walks
 };
 
 struct ConvCfg {
