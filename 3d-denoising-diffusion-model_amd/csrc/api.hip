@@ -28,7 +28,8 @@ extern "C" {
 int ddpm3d_abi_version(void) { return DDPM3D_ABI_VERSION; }
 const char* ddpm3d_last_error(void) { return g_err; }
 
-static bool prec_ok(int p) { return p >= DDPM3D_PREC_F32 && p <= DDPM3D_PREC_F16X3_WZ; }
+static bool prec_ok(int p) { return p >= DDPM3D_PREC_F32 && p <= DDPM3D_PREC_F16_WZ; }
+static bool prec_wz(int p) { return p == DDPM3D_PREC_F16X3_WZ || p == DDPM3D_PREC_F16_WZ; }
 
 // the Winograd-D form exists for 3x3x3 layers whose couts fill whole 128-wide workgroups
 static bool wz_layer_ok(int Cout, int Cin, int ksize) {
@@ -37,7 +38,7 @@ static bool wz_layer_ok(int Cout, int Cin, int ksize) {
 
 size_t ddpm3d_packed_weight_bytes(int Cout, int Cin, int ksize, int precision) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3) || !prec_ok(precision)) return 0;
-    if (precision == DDPM3D_PREC_F16X3_WZ && !wz_layer_ok(Cout, Cin, ksize)) return 0;
+    if (prec_wz(precision) && !wz_layer_ok(Cout, Cin, ksize)) return 0;
     return ddpm3d_packed_bytes(Cout, Cin, ksize, precision);
 }
 
@@ -47,7 +48,7 @@ int ddpm3d_pack_conv_weight(const float* w, int Cout, int Cin, int ksize, int pr
         return fail(DDPM3D_EINVAL, "pack_conv_weight: bad arguments (Cout=%d Cin=%d k=%d precision=%d)", Cout,
                     Cin, ksize, precision);
     if (!aligned16(out)) return fail(DDPM3D_EINVAL, "pack_conv_weight: w_packed must be 16-byte aligned");
-    if (precision == DDPM3D_PREC_F16X3_WZ && !wz_layer_ok(Cout, Cin, ksize))
+    if (prec_wz(precision) && !wz_layer_ok(Cout, Cin, ksize))
         return fail(DDPM3D_ENOSUP, "pack_conv_weight: the Winograd-D form needs ksize 3, Cout %% 128 == 0, "
                                    "Cin %% 16 == 0 (got Cout=%d Cin=%d k=%d)", Cout, Cin, ksize);
     return launched(ddpm3d_launch_pack(w, Cout, Cin, ksize, precision, out, (hipStream_t)stream),
@@ -100,7 +101,7 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
 
     ConvCfg c = ddpm3d_conv_cfg(d->N, d->D, d->H, d->W, d->Cin, d->Cout, d->ksize);
     c.PREC = d->precision;
-    if (d->precision == DDPM3D_PREC_F16X3_WZ &&
+    if (prec_wz(d->precision) &&
         !(wz_layer_ok(d->Cout, d->Cin, d->ksize) && c.TXL == 3 && c.WN == 4 && c.MT == 4 &&
           (d->in_mode == DDPM3D_IN_SAME || d->in_mode == DDPM3D_IN_UP)))
         return fail(DDPM3D_ENOSUP, "conv3d: the Winograd-D form needs ksize 3, Cout %% 128 == 0, H and W >= 8 "

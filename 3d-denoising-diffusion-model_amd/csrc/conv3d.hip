@@ -418,7 +418,8 @@ hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) 
         case 0: return ddpm3d_launch_conv_p0(k, c, st);
         case 1: return ddpm3d_launch_conv_p1(k, c, st);
         case 2: return ddpm3d_launch_conv_p2(k, c, st);
-        case 3: return ddpm3d_launch_conv_wz(k, c, st);
+        case 3:
+        case 4: return ddpm3d_launch_conv_wz(k, c, st);
     }
     return hipErrorInvalidValue;
 }
@@ -438,7 +439,8 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     // amortise a lone workgroup's un-overlapped prologue and epilogue).  It ties the default
     // kernel within 1-2 % (r01), so the default stays the simpler one.
     static const int wz2 = [] { const char* e = getenv("DDPM3D_WZ2"); return e ? atoi(e) : 0; }();
-    if (k.D % 4 == 0 && (wz2 > 0 || (wz2 < 0 && k.chunks_per_split >= 16))) {
+    const bool f16 = c.PREC == DDPM3D_PREC_F16_WZ;   // one MFMA per product: wave-specialised kernel only
+    if (!f16 && k.D % 4 == 0 && (wz2 > 0 || (wz2 < 0 && k.chunks_per_split >= 16))) {
         static const hipError_t attr =
             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wz2_kernel<4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds));
@@ -451,12 +453,15 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     // where it measured 2-3 % faster than the kernel below (r01: 0.463 / 0.874 vs 0.472 / 0.892 ms
     // on 128->128 / 256->128 @ 64^3) -- on the small levels its lone workgroup per CU loses 3-7 %
     static const int wzs_env = [] { const char* e = getenv("DDPM3D_WZS"); return e ? atoi(e) : -1; }();
-    const int wzs = wzs_env >= 0 ? wzs_env : ((long long)gx * gy * k.ksplit >= 2048 ? 1 : 0);
+    // The f16 form (one MFMA per product, 64 cycles of MFMA per tap) gets a 9-tap weight ring and
+    // A operands 3 taps ahead (~510 / ~190 cycles of cover; 12 / 5 spilled 84 bytes).
+    const int wzs = f16 ? 3 : (wzs_env >= 0 ? wzs_env : ((long long)gx * gy * k.ksplit >= 2048 ? 1 : 0));
     if (wzs != 0) {
-        const void* fn = wzs == 1 ? reinterpret_cast<const void*>(&conv3d_wzs_kernel<4, 1>)
-                                  : reinterpret_cast<const void*>(&conv3d_wzs_kernel<4, 2>);
-        static hipError_t attr1 = hipErrorUnknown, attr2 = hipErrorUnknown;
-        hipError_t& attr = wzs == 1 ? attr1 : attr2;
+        const void* fn = wzs == 1   ? reinterpret_cast<const void*>(&conv3d_wzs_kernel<4, 1, true>)
+                         : wzs == 2 ? reinterpret_cast<const void*>(&conv3d_wzs_kernel<4, 2, true>)
+                                    : reinterpret_cast<const void*>(&conv3d_wzs_kernel<9, 3, false>);
+        static hipError_t attrs[3] = {hipErrorUnknown, hipErrorUnknown, hipErrorUnknown};
+        hipError_t& attr = attrs[wzs == 1 ? 0 : (wzs == 2 ? 1 : 2)];
         if (attr == hipErrorUnknown)
             attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
         if (attr != hipSuccess) return attr;
@@ -474,9 +479,11 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
         const int zgroups = (k.tilesZ + k2.ztiles - 1) / k2.ztiles;
         const int gxs = k.N * zgroups * k.tilesY * k.tilesX;
         if (wzs == 1)
-            hipLaunchKernelGGL((conv3d_wzs_kernel<4, 1>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
+            hipLaunchKernelGGL((conv3d_wzs_kernel<4, 1, true>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
+        else if (wzs == 2)
+            hipLaunchKernelGGL((conv3d_wzs_kernel<4, 2, true>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
         else
-            hipLaunchKernelGGL((conv3d_wzs_kernel<4, 2>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
+            hipLaunchKernelGGL((conv3d_wzs_kernel<9, 3, false>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
         return hipGetLastError();
     }
     // DDPM3D_WZ_DB=1 selects the double-buffered variant (one barrier per chunk, staging spread

@@ -148,7 +148,7 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
 // f16 [tap][ci/16][hi|lo][CoutPad][16] followed by CoutPad fp32 output scales for PREC 1
 static inline size_t ddpm3d_packed_bytes(int Cout, int Cin, int ksize, int prec) {
     // Winograd-D form: 4 transformed depth taps x 3 x 3 = 36 instead of 27
-    const size_t taps = prec == DDPM3D_PREC_F16X3_WZ ? 36 : (size_t)ksize * ksize * ksize;
+    const size_t taps = (prec == DDPM3D_PREC_F16X3_WZ || prec == DDPM3D_PREC_F16_WZ) ? 36 : (size_t)ksize * ksize * ksize;
     const size_t body = taps * ddpm3d_cin_pad(Cin) * ddpm3d_cout_pad(Cout) * 4;
     return prec != 0 ? body + (size_t)ddpm3d_cout_pad(Cout) * 4 : body;  // modes 1 and 2 share the image
 }

@@ -30,7 +30,9 @@
 #pragma once
 #include "conv3d_db.h"
 
-template <int RING, int AHEAD>
+// X3: three f16 MFMAs per product on hi/lo-split operands (DDPM3D_PREC_F16X3_WZ); false: one MFMA
+// on the hi halves of the same packed image and LDS layout (DDPM3D_PREC_F16_WZ)
+template <int RING, int AHEAD, bool X3>
 __global__ __launch_bounds__(512, 2) void conv3d_wzs_kernel(const ConvK p) {
     constexpr int CK = DDPM3D_CONV_CK, NT = 36;
     constexpr int TX = 8, TXL = 3, TYL = 3;
@@ -89,9 +91,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_wzs_kernel(const ConvK p) {
             const bool ok = idx < HC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
             vox0[i] = ok ? ((n * p.D + 2 * tz_first) * hs.Hs + (y >> up_shift)) * hs.Ws + (x >> up_shift) : -1;
         }
-        f32x4 raw[NL][NP];
-        // item `it`'s raw loads (its HaloSrc must be in `hs`)
-        auto issue_raw = [&](const int it) {
+        // Two raw-value register sets (A: even items, B: odd items), each with its HaloSrc: item
+        // i+2's loads are issued BEFORE item i+1 is staged, so their memory latency runs beside a
+        // whole item of staging instead of sitting on the loaders' critical path (with one set
+        // the loaders took ~6k cycles per item, ~3k of it waiting -- as long as the 6.9k cycles of
+        // MFMA they are supposed to hide behind).  The loader role has registers to spare.
+        f32x4 rawA[NL][NP], rawB[NL][NP];
+        HaloSrc hsB = hs;
+        // item `it`'s raw loads into `raw`, addressed by its HaloSrc `hs`
+        auto issue_raw = [&](f32x4 (&raw)[NL][NP], const HaloSrc& hs, const int it) {
             const int zi = it / nch;
             const int z0 = 2 * (tz_first + zi);
             const __amdgpu_buffer_rsrc_t srsrc = make_rsrc(hs.src, hs.src_bytes);
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wzs_kernel(const ConvK p) {
                 }
         };
         // raw -> d_k -> the four transformed planes V_j, x8, f16 hi/lo split, into the image at `buf`
-        auto stage = [&](unsigned char* buf, const int it) {
+        auto stage = [&](f32x4 (&raw)[NL][NP], const HaloSrc& hs, unsigned char* buf, const int it) {
             const int z0 = 2 * (tz_first + it / nch);
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
@@ -136,31 +144,49 @@ __global__ __launch_bounds__(512, 2) void conv3d_wzs_kernel(const ConvK p) {
                         }
                         unsigned char* vrow = buf + (j * RZ + hy * RY + hx * VS) * 16;
                         *reinterpret_cast<h4*>(vrow + q * 8) = hi;
-                        *reinterpret_cast<h4*>(vrow + 32 + q * 8) = lo;
+                        if (X3) *reinterpret_cast<h4*>(vrow + 32 + q * 8) = lo;
                     }
                 }
             }
         };
 
+        auto item_src = [&](const int it) { return halo_src<CK>(p, n, chunk_begin + it % nch, q); };
         if (total > 0) {
-            issue_raw(0);
-            stage(lds, 0);
+            issue_raw(rawA, hs, 0);
             if (total > 1) {
-                hs = halo_src<CK>(p, n, chunk_begin + (1 % nch), q);   // nch == 1: the next tile's chunk
-                issue_raw(1);
+                hsB = item_src(1);
+                issue_raw(rawB, hsB, 1);
+            }
+            stage(rawA, hs, lds, 0);
+            if (total > 2) {
+                hs = item_src(2);
+                issue_raw(rawA, hs, 2);
             }
         }
         __syncthreads();                                   // image 0 ready
+        // During item `it` (compute waves read image par): stage item it+1 from its set into
+        // image par^1, then refill that set with item it+3.  Two items per trip so that the sets
+        // are indexed statically.  Exactly `total` barriers, like the compute role.
         int par = 0;
-        for (int it = 0; it < total; ++it) {
+        for (int it = 0; it < total; it += 2) {
             if (it + 1 < total) {
-                stage(lds + (par ^ 1) * BUF, it + 1);      // `hs` still describes item it+1
-                if (it + 2 < total) {
-                    hs = halo_src<CK>(p, n, chunk_begin + (it + 2) % nch, q);
-                    issue_raw(it + 2);
+                stage(rawB, hsB, lds + (par ^ 1) * BUF, it + 1);
+                if (it + 3 < total) {
+                    hsB = item_src(it + 3);
+                    issue_raw(rawB, hsB, it + 3);
                 }
             }
             __syncthreads();                               // image par^1 ready, image par free
+            par ^= 1;
+            if (it + 1 >= total) break;
+            if (it + 2 < total) {
+                stage(rawA, hs, lds + (par ^ 1) * BUF, it + 2);
+                if (it + 4 < total) {
+                    hs = item_src(it + 4);
+                    issue_raw(rawA, hs, it + 4);
+                }
+            }
+            __syncthreads();
             par ^= 1;
         }
         return;
@@ -189,18 +215,18 @@ __global__ __launch_bounds__(512, 2) void conv3d_wzs_kernel(const ConvK p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[j][t][i] = 0.0f;
 
-    u32x4 bq[RING][2];  // weight ring: slot = tap % RING, [hi|lo]
+    u32x4 bq[RING][X3 ? 2 : 1];  // weight ring: slot = tap % RING, [hi|lo]
     auto load_w = [&](const int slot, const unsigned off) {
         bq[slot][0] = buffer_load16(wrsrc, wlane, off);
-        bq[slot][1] = buffer_load16(wrsrc, wlane, off + wpart);
+        if (X3) bq[slot][X3 ? 1 : 0] = buffer_load16(wrsrc, wlane, off + wpart);
     };
-    h8 af[AS][2][2];    // A operands: slot = tap % AS, [row tile][hi|lo]
+    h8 af[AS][2][X3 ? 2 : 1];    // A operands: slot = tap % AS, [row tile][hi|lo]
     auto load_a = [&](const int slot, const unsigned char* base, const int tap) {
         const int off = ((tap / 9) * RZ + ((tap / 3) % 3) * RY + (tap % 3) * VS) * 16;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             af[slot][t][0] = *reinterpret_cast<const h8*>(base + arow[t] + off);
-            af[slot][t][1] = *reinterpret_cast<const h8*>(base + arow[t] + off + 32);
+            if (X3) af[slot][t][X3 ? 1 : 0] = *reinterpret_cast<const h8*>(base + arow[t] + off + 32);
         }
     };
 
@@ -234,14 +260,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_wzs_kernel(const ConvK p) {
             __builtin_amdgcn_sched_barrier(0);
             const int j = tap / 9;
             const h8 bhi = __builtin_bit_cast(h8, bq[tap % RING][0]);
-            const h8 blo = __builtin_bit_cast(h8, bq[tap % RING][1]);
             // per accumulator the order stays lo*hi, hi*lo, hi*hi; the two row tiles alternate
+            if (X3) {
+                const h8 blo = __builtin_bit_cast(h8, bq[tap % RING][X3 ? 1 : 0]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap % AS][t][1], bhi, acc[j][t], 0, 0, 0);
+                for (int t = 0; t < 2; ++t)
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap % AS][t][X3 ? 1 : 0], bhi, acc[j][t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap % AS][t][0], blo, acc[j][t], 0, 0, 0);
+                for (int t = 0; t < 2; ++t)
+                    acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap % AS][t][0], blo, acc[j][t], 0, 0, 0);
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap % AS][t][0], bhi, acc[j][t], 0, 0, 0);

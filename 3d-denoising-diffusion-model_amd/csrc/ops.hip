@@ -129,7 +129,7 @@ __global__ void pack_wz_kernel(const float* __restrict__ w, const float* __restr
 
 hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, int prec, void* out, hipStream_t st) {
     const int CoutPad = ddpm3d_cout_pad(Cout), CinPad = ddpm3d_cin_pad(Cin);
-    if (prec == DDPM3D_PREC_F16X3_WZ) {   // [f16 image of 36 transformed taps][CoutPad fp32 wscale]
+    if (prec == DDPM3D_PREC_F16X3_WZ || prec == DDPM3D_PREC_F16_WZ) {   // [f16 image of 36 transformed taps][CoutPad fp32 wscale]
         const size_t total = (size_t)36 * CinPad * CoutPad;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;

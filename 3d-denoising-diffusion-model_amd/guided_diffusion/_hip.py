@@ -21,9 +21,11 @@ ACT_NONE, ACT_SILU = 0, 1
 OUT_NDHWC, OUT_NCDHW = 0, 1
 F_LEARN_SIGMA, F_PREDICT_XSTART, F_CLIP = 1, 2, 4
 NCOEF = 8
-PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X3_WZ = 0, 1, 2, 3
+PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X3_WZ, PREC_F16_WZ = 0, 1, 2, 3, 4
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16}
-ABI_VERSION = 5
+# the Winograd-along-depth form of a mode (same arithmetic, 2/3 of the MFMAs), where one exists
+WINOGRAD_OF = {PREC_F16X3: PREC_F16X3_WZ, PREC_F16: PREC_F16_WZ}
+ABI_VERSION = 6
 
 _fp = C.c_void_p
 

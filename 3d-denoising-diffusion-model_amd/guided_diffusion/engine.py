@@ -82,11 +82,11 @@ class UNetEngine:
                 w = t if t.dim() == 5 else t.reshape(t.shape[0], t.shape[1], 1, 1, 1)
                 prec = H.PRECISIONS[precision]
                 self.conv[base] = PackedConv(w, params[base + ".bias"], prec, st)
-                # f16x3: the big 3x3x3 layers also get the Winograd-along-depth form (1.5x fewer
-                # MFMAs); conv_step picks it per call where the shape / input mode allow
-                if (prec == H.PREC_F16X3 and self.winograd and w.shape[2] == 3 and w.shape[0] % 128 == 0
+                # f16x3 / f16: the big 3x3x3 layers also get the Winograd-along-depth form (1.5x
+                # fewer MFMAs); conv_step picks it per call where the shape / input mode allow
+                if (prec in H.WINOGRAD_OF and self.winograd and w.shape[2] == 3 and w.shape[0] % 128 == 0
                         and w.shape[1] % 16 == 0):
-                    self.conv[base].wz = PackedConv(w, params[base + ".bias"], H.PREC_F16X3_WZ, st)
+                    self.conv[base].wz = PackedConv(w, params[base + ".bias"], H.WINOGRAD_OF[prec], st)
         # fuse every ResBlock's emb_layers Linear into one [total, ted] matrix
         ws, bs, self.film_off = [], [], {}
         off = 0

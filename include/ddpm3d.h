@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DDPM3D_ABI_VERSION 5
+#define DDPM3D_ABI_VERSION 6
 
 enum {
     DDPM3D_OK = 0,
@@ -140,7 +140,11 @@ enum {
      * while they are staged, the outputs in the epilogue).  Available for ksize 3, Cout a
      * multiple of 128, H and W >= 8, input modes SAME / UP; other calls return DDPM3D_ENOSUP
      * and must use the F16X3 packing of the same weights. */
-    DDPM3D_PREC_F16X3_WZ = 3
+    DDPM3D_PREC_F16X3_WZ = 3,
+    /* F16 arithmetic (one MFMA per product on f16-rounded operands, as DDPM3D_PREC_F16) on the
+     * same Winograd-D form and the same packed image as DDPM3D_PREC_F16X3_WZ (its hi halves);
+     * same availability rule. */
+    DDPM3D_PREC_F16_WZ = 4
 };
 
 /* bytes of the packed form of an (Cout, Cin, k, k, k) weight for a precision mode */

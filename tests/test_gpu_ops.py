@@ -174,6 +174,34 @@ def test_conv3d_f16_mode_is_half_precision_grade(hc):
     assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(xi, wi, bi, padding=1))
 
 
+@pytest.mark.parametrize("N,D,Hh,W,ci,co", [
+    (1, 4, 16, 16, 64, 128),
+    (2, 5, 8, 24, 32, 256),      # odd D, batch 2, two cout blocks
+    (1, 64, 8, 8, 256, 384),     # split-K + reduce kernel
+])
+def test_conv3d_f16_winograd_depth_form(hc, N, D, Hh, W, ci, co):
+    """precision 4: the f16 mode (one MFMA per product) on the Winograd-D form.  The transformed
+    operands are rounded to f16 (weights (g0 +- g1 + g2)/2 at pack time, inputs d_a +- d_b while
+    staged), so the bar is the f16 mode's: ~1e-3 of the output range."""
+    x = rnd(N, ci, D, Hh, W, seed=31)
+    w = rnd(co, ci, 3, 3, 3, seed=32, scale=0.03)
+    b = rnd(co, seed=33)
+    ref = F.conv3d(x, w, b, padding=1)
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (D, Hh, W), precision=4)
+    e = rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy())
+    assert 1e-6 < e < 2e-3, e
+    # statistics describe the tensor that was written (not the exact conv): compare to it
+    check_stats(stats, hc.to_ncdhw(out.cpu()))
+    # small even integers: every transformed operand ((g0 +- g1 + g2)/2, d_a +- d_b) is an integer
+    # that f16 holds exactly, so the result is exact
+    g = np.random.default_rng(6)
+    xi = torch.from_numpy(g.integers(-3, 4, (1, 16, 4, 9, 10)).astype(np.float32))
+    wi = torch.from_numpy((2 * g.integers(-2, 3, (128, 16, 3, 3, 3))).astype(np.float32))
+    bi = torch.from_numpy(g.integers(-5, 6, (128,)).astype(np.float32))
+    out, _, _ = hc.conv3d([hc.to_ndhwc(xi).cuda()], wi.cuda(), bi.cuda(), (4, 9, 10), precision=4)
+    assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(xi, wi, bi, padding=1))
+
+
 def test_conv3d_k1_concat(hc):
     xa, xb = rnd(2, 32, 3, 8, 8, seed=1), rnd(2, 16, 3, 8, 8, seed=2)
     w = rnd(64, 48, 1, 1, 1, seed=3, scale=0.1)
