@@ -196,6 +196,9 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const float* run = st + ((size_t)n * Cs + cs) * rows * 2;
     if ((reinterpret_cast<uintptr_t>(run) & 15) == 0) {
         const size_t pairs = items / 2;              // float4 = two (sum, sumsq) entries
+        // unrolled: eight independent 16-byte loads in flight per thread instead of a
+        // load -> convert -> add chain (a 64^3-level group is 64 KB: 16 loads per thread)
+#pragma unroll 8
         for (size_t i = threadIdx.x; i < pairs; i += blockDim.x) {
             const float4 v = *reinterpret_cast<const float4*>(run + i * 4);
             s1 += (double)v.x + (double)v.z;
