@@ -215,12 +215,20 @@ int ddpm3d_subsample_hw2(const float* in, int N, int D, int H, int W, int C, flo
     return launched(ddpm3d_launch_subsample_hw2(in, N, D, H, W, C, out, (hipStream_t)stream), "subsample_hw2");
 }
 
-int ddpm3d_attention(const float* qkv, int N, int T, int heads, int head_channels, float* out, void* stream) {
+int ddpm3d_attention_p(const float* qkv, int N, int T, int heads, int head_channels, int precision, float* out,
+                       void* stream) {
     if (!qkv || !out || N <= 0 || T <= 0 || heads <= 0) return fail(DDPM3D_EINVAL, "attention: bad arguments");
     if (head_channels != 32 && head_channels != 64 && head_channels != 128)
         return fail(DDPM3D_ENOSUP, "attention: %d channels per head (32, 64 or 128 are built)", head_channels);
+    if (precision != DDPM3D_PREC_F32 && precision != DDPM3D_PREC_F16X3)
+        return fail(DDPM3D_ENOSUP, "attention: precision %d (F32 and F16X3 are built)", precision);
     if (!aligned16(qkv) || !aligned16(out)) return fail(DDPM3D_EINVAL, "attention: buffers must be 16-byte aligned");
-    return launched(ddpm3d_launch_attention(qkv, N, T, heads, head_channels, out, (hipStream_t)stream), "attention");
+    return launched(ddpm3d_launch_attention(qkv, N, T, heads, head_channels, precision, out, (hipStream_t)stream),
+                    "attention");
+}
+
+int ddpm3d_attention(const float* qkv, int N, int T, int heads, int head_channels, float* out, void* stream) {
+    return ddpm3d_attention_p(qkv, N, T, heads, head_channels, DDPM3D_PREC_F32, out, stream);
 }
 
 static int step_args_ok(const float* mo, const float* x, const float* noise, const float* coef,

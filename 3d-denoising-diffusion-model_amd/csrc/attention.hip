@@ -17,6 +17,7 @@
 // (an MFMA's k index is summed, so each half simply supplies the keys it holds; the V^T
 // operand is read from LDS in the matching key order).  No transpose, no LDS round trip.
 #include <hip/hip_runtime.h>
+#include "../../include/ddpm3d.h"
 #include "ops.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -134,9 +135,229 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
-hipError_t ddpm3d_launch_attention(const float* qkv, int N, int T, int heads, int ch, float* out,
+// ---------------------------------------------------------------------------------------------
+// The same algorithm on v_mfma_f32_32x32x16_f16 with every operand split x = hi + lo into two f16
+// (a*b = lo*hi + hi*lo + hi*hi, each f16 x f16 product exact in fp32: the convs' f16x3 arithmetic,
+// conv3d.hip) -- 16/3 of the fp32 MFMA rate; r01 config 5: the fp32 kernel was 43 % of a step.
+//
+//   S^T tile = K Q^T :  A = K[key][16 c] from LDS (f16 hi / lo rows), B = Q^T from registers
+//   O^T tile = V^T P^T: A = V^T[c][16 keys] from LDS, B = P^T straight from the score registers.
+// As in the fp32 kernel a lane's 16 score registers are 16 of the tile's 32 keys, in the order
+// key(r) = (r&3) + 8*(r>>2) + 4*half.  An MFMA sums over its k index, so the second product may
+// take the keys in ANY order as long as A and B agree: B's k-step s2 is simply registers
+// 8*s2..8*s2+7, and V^T is stored in LDS with the keys of each 16-key group permuted to
+// pos(k) = ((k>>2)&1)*8 + ((k>>3)&1)*4 + (k&3), which makes the matching 8 keys one 16-byte read.
+// Rows are padded to an ODD number of 16-byte slots: a ds_read_b128 is served in 16-lane groups
+// whose rows are distinct mod 16, so odd strides are conflict-free (MI355X_MICROARCH.md, LDS).
+//
+// Power-of-two scales keep the lo parts normal f16: Q, K, V x2^3 (clamped to +-60000 like the
+// convs' activations), P in [0,1] x2^12; the scores are un-scaled (x2^-6, exact) before the fp32
+// softmax and the output's 2^15 is folded into the final 1/l.  exp is exp2(x*log2 e) (v_exp_f32).
+typedef _Float16 ah8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ah4 __attribute__((ext_vector_type(4)));
+
+struct HiLo { _Float16 hi, lo; };
+__device__ __forceinline__ HiLo split_f16(float x, float scale) {
+    const float s = fminf(fmaxf(x * scale, -60000.0f), 60000.0f);
+    HiLo r;
+    r.hi = (_Float16)s;
+    r.lo = (_Float16)(s - (float)r.hi);
+    return r;
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv, int T, int heads,
+                                                           float* __restrict__ out) {
+    constexpr int KT = 32;                    // keys per tile
+    constexpr int KS = CH / 16;               // k-steps of the first product
+    constexpr int CT = CH / 32;               // 32-channel output tiles
+    constexpr int KROW = CH * 2 + 16;         // bytes per K row (f16): CH/8 + 1 slots, odd
+    constexpr int VROW = KT * 2 + 16;         // bytes per V^T row (32 keys, f16): 5 slots
+    constexpr float QKV_SCALE = 8.0f, P_SCALE = 4096.0f;
+    static_assert(((KROW / 16) & 1) == 1 && ((VROW / 16) & 1) == 1, "odd slot strides");
+    __shared__ __attribute__((aligned(16))) unsigned char Kh[KT * KROW], Kl[KT * KROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Vh[CH * VROW], Vl[CH * VROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = lane & 31, half = lane >> 5;
+    const int nh = blockIdx.y;
+    const int n = nh / heads, head = nh % heads;
+    const int C3 = heads * 3 * CH;
+    const float* base = qkv + (size_t)n * T * C3 + (size_t)head * 3 * CH;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int tq = q0 + qi;
+    const bool qvalid = tq < T;
+
+    // Q^T operand: lane (query, half) supplies Q[query][16 s + 8 half .. +8] at k-step s, with
+    // the softmax scale s^2 = CH^-1/2 folded in before the split
+    ah8 qhi[KS], qlo[KS];
+    {
+        const float scale = 1.0f / sqrtf((float)CH);
+        const float* qrow = base + (size_t)(qvalid ? tq : 0) * C3;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * half);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * half + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const HiLo a = split_f16(v0[i] * scale, QKV_SCALE), b = split_f16(v1[i] * scale, QKV_SCALE);
+                qhi[s][i] = a.hi; qlo[s][i] = a.lo;
+                qhi[s][4 + i] = b.hi; qlo[s][4 + i] = b.lo;
+            }
+        }
+    }
+
+    f32x16 oacc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[c][i] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    // The tile's K and V rows are fetched ONE TILE AHEAD into registers (item = (K or V, key j,
+    // channel quad c4), NI per thread): the global-load latency runs beside the previous tile's
+    // MFMAs instead of between two barriers (without it a tile took ~3.9 us for 0.4 us of MFMA).
+    constexpr int NI = KT * (CH / 4) * 2 / 256;
+    static_assert(KT * (CH / 4) * 2 % 256 == 0, "whole items per thread");
+    f32x4 pre[NI];
+    auto fetch = [&](const int k0) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int idx = tid + it * 256;
+            const int which = idx / (KT * (CH / 4));        // 0 = K, 1 = V
+            const int r = idx % (KT * (CH / 4));
+            const int j = r / (CH / 4), c4 = r % (CH / 4);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            pre[it] = k0 + j < T
+                          ? *reinterpret_cast<const f32x4*>(base + (size_t)(k0 + j) * C3 + (which + 1) * CH + c4 * 4)
+                          : zero;                            // keys beyond T are zeros
+        }
+    };
+    fetch(0);
+
+    for (int k0 = 0; k0 < T; k0 += KT) {
+        __syncthreads();
+        // split the prefetched rows into the LDS tile
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int idx = tid + it * 256;
+            const int which = idx / (KT * (CH / 4));
+            const int r = idx % (KT * (CH / 4));
+            const int j = r / (CH / 4), c4 = r % (CH / 4);
+            const f32x4 v = pre[it];
+            ah4 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const HiLo a = split_f16(v[i], QKV_SCALE);
+                hi[i] = a.hi; lo[i] = a.lo;
+            }
+            if (which == 0) {
+                *reinterpret_cast<ah4*>(Kh + j * KROW + c4 * 8) = hi;
+                *reinterpret_cast<ah4*>(Kl + j * KROW + c4 * 8) = lo;
+            } else {
+                // V^T[c][pos(key)]: the key order the score registers of a lane half are in
+                const int k16 = j & 15;
+                const int pos = (j & 16) + ((k16 >> 2) & 1) * 8 + ((k16 >> 3) & 1) * 4 + (k16 & 3);
+                // Channel c = 4 c4 + i lives in LDS row i * (CH/4) + c4: the lanes of a wave (consecutive
+                // c4) then write CONSECUTIVE rows, 20 dwords apart = 16 distinct banks.  (Rows 4 apart,
+                // the natural order, are 80 dwords apart = 4 banks: a 16-way conflict on every one of
+                // these 2-byte stores.)  The output rows come out in that order; see the epilogue.
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    *reinterpret_cast<_Float16*>(Vh + (i * (CH / 4) + c4) * VROW + pos * 2) = hi[i];
+                    *reinterpret_cast<_Float16*>(Vl + (i * (CH / 4) + c4) * VROW + pos * 2) = lo[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (k0 + KT < T) fetch(k0 + KT);
+
+        // S^T[key][query] = sum_c K[key][c] * Q[query][c]   (x 2^6)
+        f32x16 sacc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc[i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const ah8 khi = *reinterpret_cast<const ah8*>(Kh + qi * KROW + (16 * s + 8 * half) * 2);
+            const ah8 klo = *reinterpret_cast<const ah8*>(Kl + qi * KROW + (16 * s + 8 * half) * 2);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(klo, qhi[s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qlo[s], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(khi, qhi[s], sacc, 0, 0, 0);
+        }
+
+        // Scores stay in their x 2^6 units (max and differences do not care); the un-scaling and
+        // exp's log2(e) are one constant in the exp2 argument.  Only the ragged last tile masks.
+        constexpr float EXP2_C = 1.44269504088896341f / (QKV_SCALE * QKV_SCALE);
+        if (k0 + KT > T) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (k0 + (r & 3) + 8 * (r >> 2) + 4 * half >= T) sacc[r] = -INFINITY;
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        const float m_new = fmaxf(m_run, tmax);           // finite: every tile has >= 1 valid key
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * EXP2_C);   // first tile: exp2(-inf) = 0
+        float psum = 0.0f;
+        ah8 phi[2], plo[2];                               // P^T operand: k-step s2 = registers 8 s2 .. 8 s2 + 7
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pr = __builtin_amdgcn_exp2f((sacc[r] - m_new) * EXP2_C);
+            psum += pr;
+            const float ps = pr * P_SCALE;                 // in [0, 4096]: no clamp needed
+            const _Float16 ph = (_Float16)ps;
+            phi[r >> 3][r & 7] = ph;
+            plo[r >> 3][r & 7] = (_Float16)(ps - (float)ph);
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+
+        // O^T[c][query] = alpha * O^T + sum_key V[key][c] * P^T[key][query]   (x 2^15)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[c][i] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const ah8 vhi = *reinterpret_cast<const ah8*>(Vh + (c * 32 + qi) * VROW + (16 * s2 + 8 * half) * 2);
+                const ah8 vlo = *reinterpret_cast<const ah8*>(Vl + (c * 32 + qi) * VROW + (16 * s2 + 8 * half) * 2);
+                oacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlo, phi[s2], oacc[c], 0, 0, 0);
+                oacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, plo[s2], oacc[c], 0, 0, 0);
+                oacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhi, phi[s2], oacc[c], 0, 0, 0);
+            }
+        }
+    }
+
+    if (!qvalid) return;
+    const float inv = 1.0f / (l_run * QKV_SCALE * P_SCALE);
+    float* orow = out + ((size_t)n * T + tq) * (heads * CH) + (size_t)head * CH;
+    // accumulator row m of tile c is LDS row R = 32 c + m, i.e. channel (R % (CH/4)) * 4 + R / (CH/4)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int R = c * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            orow[(R % (CH / 4)) * 4 + R / (CH / 4)] = oacc[c][r] * inv;
+        }
+    }
+}
+
+hipError_t ddpm3d_launch_attention(const float* qkv, int N, int T, int heads, int ch, int precision, float* out,
                                    hipStream_t st) {
     dim3 grid((T + 127) / 128, N * heads);
+    if (precision != DDPM3D_PREC_F32) {
+        if (ch == 64)
+            hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, st, qkv, T, heads, out);
+        else if (ch == 32)
+            hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, st, qkv, T, heads, out);
+        else if (ch == 128)
+            hipLaunchKernelGGL(attention_x3_kernel<128>, grid, dim3(256), 0, st, qkv, T, heads, out);
+        else
+            return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (ch == 64)
         hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, st, qkv, T, heads, out);
     else if (ch == 32)

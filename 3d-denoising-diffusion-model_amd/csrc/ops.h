@@ -20,5 +20,5 @@ hipError_t ddpm3d_launch_subsample_hw2(const float* in, int N, int D, int H, int
 hipError_t ddpm3d_launch_sample_step(bool ddim, const float* mo, const float* x, const float* noise,
                                      const float* coef, const int64_t* t_idx, int N, int voxels, int flags,
                                      float eta, float* sample, float* pred_xstart, hipStream_t st);
-hipError_t ddpm3d_launch_attention(const float* qkv, int N, int T, int heads, int ch, float* out,
+hipError_t ddpm3d_launch_attention(const float* qkv, int N, int T, int heads, int ch, int precision, float* out,
                                    hipStream_t st);

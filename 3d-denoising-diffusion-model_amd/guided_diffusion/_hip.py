@@ -25,7 +25,7 @@ PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X3_WZ, PREC_F16_WZ = 0, 1, 2, 3, 4
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16}
 # the Winograd-along-depth form of a mode (same arithmetic, 2/3 of the MFMAs), where one exists
 WINOGRAD_OF = {PREC_F16X3: PREC_F16X3_WZ, PREC_F16: PREC_F16_WZ}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _fp = C.c_void_p
 
@@ -59,6 +59,7 @@ EXPORTS = {
     "ddpm3d_timestep_embedding": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ddpm3d_linear": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp, C.c_int, _fp]),
     "ddpm3d_attention": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ddpm3d_attention_p": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_ncdhw_to_ndhwc": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_ndhwc_to_ncdhw": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_subsample_hw2": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),

@@ -345,8 +345,12 @@ class _Plan:
         a = self.new_act(Cn, x.D, x.H, x.W)
         # two T x T x ch products per head (the reference's count_flops_attn, unet.py:308-325)
         self.conv_meta[len(self.steps)] = ("attention_ch%d" % ch, 4.0 * N * heads * float(x.voxels) ** 2 * ch)
-        self.steps.append((eng.lib.ddpm3d_attention,
-                           [H.ptr(qkv.buf), N, x.voxels, heads, ch, H.ptr(a.buf), 0]))
+        # the two products in the model's arithmetic: exact fp32 MFMA in the "f32" mode, fp32-grade
+        # f16x3 otherwise (in the "f16" mode too: the reference's fp16 torso keeps the softmax in
+        # fp32 (unet.py:351), and f16-rounded scores would cost more accuracy than the convs do)
+        aprec = H.PREC_F32 if eng.precision == "f32" else H.PREC_F16X3
+        self.steps.append((eng.lib.ddpm3d_attention_p,
+                           [H.ptr(qkv.buf), N, x.voxels, heads, ch, aprec, H.ptr(a.buf), 0]))
         y = self.new_act(Cn, x.D, x.H, x.W)
         self.conv_step(eng.conv[p + ".proj_out"], [a], y, res=x, res_mode=H.RES_SAME)
         return y

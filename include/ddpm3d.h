@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DDPM3D_ABI_VERSION 6
+#define DDPM3D_ABI_VERSION 7
 
 enum {
     DDPM3D_OK = 0,
@@ -202,6 +202,12 @@ int ddpm3d_linear(const float* in, int rows, int K, const float* w, const float*
  */
 int ddpm3d_attention(const float* qkv, int N, int T, int heads, int head_channels,
                      float* out, void* stream);
+/* The same with the arithmetic of the two products chosen like a conv's: DDPM3D_PREC_F32 (exact fp32
+ * MFMA, what ddpm3d_attention runs) or DDPM3D_PREC_F16X3 (fp32-grade products from three f16 MFMAs
+ * on hi/lo-split q, k, v and softmax weights; 16/3 of the fp32 MFMA rate).  The softmax itself is
+ * fp32 in both (unet.py:351). */
+int ddpm3d_attention_p(const float* qkv, int N, int T, int heads, int head_channels, int precision,
+                       float* out, void* stream);
 
 /* layout changes at the API edge */
 int ddpm3d_ncdhw_to_ndhwc(const float* in, int N, int C, int voxels, float* out, void* stream);

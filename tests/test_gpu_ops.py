@@ -391,23 +391,33 @@ def test_linear_and_timestep_embedding(hc):
         assert rel_err(o.cpu().numpy(), ref.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("N,T,heads,ch", [(1, 128, 2, 32), (2, 200, 3, 64), (1, 77, 1, 32), (1, 512, 2, 64)])
-def test_attention_core_vs_legacy_reference(hc, N, T, heads, ch):
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("N,T,heads,ch,scale", [(1, 128, 2, 32, 1.0), (2, 200, 3, 64, 1.0), (1, 77, 1, 32, 1.0),
+                                                (1, 512, 2, 64, 1.0), (1, 300, 2, 128, 1.0),
+                                                (1, 256, 1, 64, 3.0),      # peaked softmax (|scores| ~ 70)
+                                                (1, 160, 2, 32, 0.02)])    # tiny activations (lo parts small)
+def test_attention_core_vs_legacy_reference(hc, N, T, heads, ch, scale, precision):
     """Streaming attention vs the materialised softmax of QKVAttentionLegacy (unet.py:337-354),
-    including T not a multiple of the 32-key tile or the 128-query block."""
+    including T not a multiple of the 32-key tile or the 128-query block, in both arithmetic
+    modes of the two products (0: exact fp32 MFMA, 1: f16x3) -- same bar."""
     import math
     import guided_diffusion._hip as H
     lib = H.load()
-    qkv = rnd(N, heads * 3 * ch, T, seed=1)                      # reference layout (N, H*3*C, T)
+    qkv = rnd(N, heads * 3 * ch, T, seed=1, scale=scale)         # reference layout (N, H*3*C, T)
     q, k, v = qkv.reshape(N * heads, ch * 3, T).split(ch, dim=1)
     s = 1 / math.sqrt(math.sqrt(ch))
     w = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s).float(), dim=-1)
     ref = torch.einsum("bts,bcs->bct", w, v).reshape(N, -1, T)    # (N, H*C, T)
     qd = qkv.permute(0, 2, 1).contiguous().cuda()                 # channels-last (N, T, H*3*C)
     out = torch.full((N, T, heads * ch), float("nan"), device="cuda")
-    H.check(lib.ddpm3d_attention(H.ptr(qd), N, T, heads, ch, H.ptr(out), H.stream()))
+    H.check(lib.ddpm3d_attention_p(H.ptr(qd), N, T, heads, ch, precision, H.ptr(out), H.stream()))
     torch.cuda.synchronize()
-    assert rel_err(out.permute(0, 2, 1).cpu().numpy(), ref.numpy()) < 1e-5
+    assert rel_err(out.permute(0, 2, 1).cpu().numpy(), ref.double().numpy()) < 1e-5
+    if precision == 0:      # the two-argument entry point is the exact mode
+        out0 = torch.full_like(out, float("nan"))
+        H.check(lib.ddpm3d_attention(H.ptr(qd), N, T, heads, ch, H.ptr(out0), H.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out0, out)
 
 
 def test_attention_rejects_unsupported_head_width(hc):
