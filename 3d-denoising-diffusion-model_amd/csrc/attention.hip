@@ -24,7 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int CH>
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, int T, int heads,
+__global__ __launch_bounds__(256, (CH == 128 ? 2 : 3)) void attention_kernel(const float* __restrict__ qkv, int T, int heads,
                                                         float* __restrict__ out) {
     constexpr int KT = 32;            // keys per tile
     constexpr int LS = CH + 1;        // LDS row stride (floats): odd -> conflict-free column reads
@@ -165,8 +165,10 @@ __device__ __forceinline__ HiLo split_f16(float x, float scale) {
     return r;
 }
 
+// (waves per SIMD stated explicitly: with the bare bound the compiler keeps the MFMA accumulators
+// in AGPRs and spends 144 v_accvgpr_read/write per tile moving them around the softmax)
 template <int CH>
-__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ qkv, int T, int heads,
+__global__ __launch_bounds__(256, (CH == 128 ? 2 : 3)) void attention_x3_kernel(const float* __restrict__ qkv, int T, int heads,
                                                            float* __restrict__ out) {
     constexpr int KT = 32;                    // keys per tile
     constexpr int KS = CH / 16;               // k-steps of the first product
