@@ -506,17 +506,19 @@ def test_conv3d_variants_agree_bitwise():
     import subprocess
     import sys
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variant_conv.py")
-    variants = [{}, {"DDPM3D_WZS": "0"}, {"DDPM3D_WZS": "1"}, {"DDPM3D_WZS": "2"}, {"DDPM3D_WZ_DB": "1", "DDPM3D_WZS": "0"},
-                {"DDPM3D_WZ2": "1"}, {"DDPM3D_WSTAT": "1"}, {"DDPM3D_WSTAT": "0"}]
+    variants = [{}, {"DDPM3D_WZS": "0"}, {"DDPM3D_WZS": "1"}, {"DDPM3D_WZS": "2"},
+                {"DDPM3D_WZS": "1", "DDPM3D_WZS_ZT": "2"}, {"DDPM3D_WZS": "1", "DDPM3D_WZS_ZT": "8"},
+                {"DDPM3D_WZ_DB": "1", "DDPM3D_WZS": "0"}, {"DDPM3D_WZ2": "1"}, {"DDPM3D_WSTAT": "1"},
+                {"DDPM3D_WSTAT": "0"}]
     outs = []
     for v in variants:
         env = {k: x for k, x in os.environ.items()
-               if k not in ("DDPM3D_WZ_DB", "DDPM3D_WZ2", "DDPM3D_WSTAT", "DDPM3D_WZS")}
+               if k not in ("DDPM3D_WZ_DB", "DDPM3D_WZ2", "DDPM3D_WSTAT", "DDPM3D_WZS", "DDPM3D_WZS_ZT")}
         env.update(v)
         r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, "variant %s failed:\n%s" % (v, r.stderr[-2000:])
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("case")]
-        assert len(lines) == 3, r.stdout
+        assert len(lines) == 6, r.stdout
         outs.append(lines)
     for v, o in zip(variants[1:], outs[1:]):
         assert o == outs[0], "variant %s differs from the default kernel:\n%s\n%s" % (v, o, outs[0])

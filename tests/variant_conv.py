@@ -30,6 +30,9 @@ def main():
         (1, 8, 16, 16, 64, 128),     # D % 4 == 0: the 8x8x4-tile kernel is eligible
         (2, 4, 8, 24, 32, 256),      # batch 2, two cout blocks
         (1, 64, 8, 8, 256, 384),     # split-K + reduce kernel, weights outweigh activations
+        (1, 5, 16, 24, 32, 128),     # odd D: three z-pairs, the last half valid; z-walk groups of 2 + 1
+        (1, 1, 9, 12, 16, 128),      # D = 1, ragged H / W: edge tiles take the general epilogue
+        (2, 10, 8, 8, 48, 128),      # five z-pairs in one tile column, batch 2
     ]
     for i, (N, D, Hh, W, ci, co) in enumerate(cases):
         x = hc.to_ndhwc(rnd(N, ci, D, Hh, W, seed=10 + i)).cuda()
