@@ -449,7 +449,9 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
         return hipGetLastError();
     }
     // wave-specialised form (conv3d_wzs.h): 512 threads, waves 0-3 compute, 4-7 stage
-    // DDPM3D_WZS: 0 never, 1 / 2 always (A operands 1 / 2 taps ahead); unset: on the big grids,
+    // DDPM3D_WZS: 0 never, 1 / 2 always (weight ring of 4 / 6 taps: 24 / 40 KB of weight loads in
+    // flight per CU -- no difference, 0.464 vs 0.471 ms, so latency x bytes-in-flight is not what
+    // caps the weight stream; A operands two taps ahead made none either); unset: on the big grids,
     // where it measured 2-3 % faster than the kernel below (r01: 0.463 / 0.874 vs 0.472 / 0.892 ms
     // on 128->128 / 256->128 @ 64^3) -- on the small levels its lone workgroup per CU loses 3-7 %
     static const int wzs_env = [] { const char* e = getenv("DDPM3D_WZS"); return e ? atoi(e) : -1; }();
@@ -458,7 +460,7 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     const int wzs = f16 ? 3 : (wzs_env >= 0 ? wzs_env : ((long long)gx * gy * k.ksplit >= 2048 ? 1 : 0));
     if (wzs != 0) {
         const void* fn = wzs == 1   ? reinterpret_cast<const void*>(&conv3d_wzs_kernel<4, 1, true>)
-                         : wzs == 2 ? reinterpret_cast<const void*>(&conv3d_wzs_kernel<4, 2, true>)
+                         : wzs == 2 ? reinterpret_cast<const void*>(&conv3d_wzs_kernel<6, 1, true>)
                                     : reinterpret_cast<const void*>(&conv3d_wzs_kernel<9, 3, false>);
         static hipError_t attrs[3] = {hipErrorUnknown, hipErrorUnknown, hipErrorUnknown};
         hipError_t& attr = attrs[wzs == 1 ? 0 : (wzs == 2 ? 1 : 2)];
@@ -481,7 +483,7 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
         if (wzs == 1)
             hipLaunchKernelGGL((conv3d_wzs_kernel<4, 1, true>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
         else if (wzs == 2)
-            hipLaunchKernelGGL((conv3d_wzs_kernel<4, 2, true>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
+            hipLaunchKernelGGL((conv3d_wzs_kernel<6, 1, true>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
         else
             hipLaunchKernelGGL((conv3d_wzs_kernel<9, 3, false>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
         return hipGetLastError();
