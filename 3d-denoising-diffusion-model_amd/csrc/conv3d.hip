@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
     };
     if (PIPE && chunk_begin < chunk_end) issue_raw(hs);
 
+    // (Tried, r01: fetching a 1x1 conv's single tap of weights a whole chunk ahead in loop-carried
+    // registers.  hipcc then waits vmcnt(0) at the top of the tap section, ahead of the new loads:
+    // 0.131 -> 0.318 ms on 256->128 @ 64^3.  Left as it was.)
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         __syncthreads();  // everyone done reading the previous chunk's tile
         // ------------------------------------------------ stage the halo tile
