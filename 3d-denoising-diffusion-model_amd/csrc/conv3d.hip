@@ -143,9 +143,11 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
     };
     if (PIPE && chunk_begin < chunk_end) issue_raw(hs);
 
-    // (Tried, r01: fetching a 1x1 conv's single tap of weights a whole chunk ahead in loop-carried
-    // registers.  hipcc then waits vmcnt(0) at the top of the tap section, ahead of the new loads:
-    // 0.131 -> 0.318 ms on 256->128 @ 64^3.  Left as it was.)
+    // (Tried, r01, for the 1x1 convs whose single tap leaves the weight ring nothing to run ahead
+    // of: (a) the tap fetched a whole chunk ahead in loop-carried registers -- hipcc then waits
+    // vmcnt(0) at the top of the tap section, ahead of the new loads: 0.131 -> 0.318 ms on 256->128
+    // @ 64^3; (b) the tap requested before the staging barriers: 0.128 -> 0.135 ms.  With three
+    // workgroups per CU the latency is already covered; those layers just move 400 MB.)
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         __syncthreads();  // everyone done reading the previous chunk's tile
         // ------------------------------------------------ stage the halo tile
