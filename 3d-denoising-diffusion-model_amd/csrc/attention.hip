@@ -317,10 +317,15 @@ __global__ __launch_bounds__(256, (CH == 128 ? 2 : 3)) void attention_x3_kernel(
         m_run = m_new;
 
         // O^T[c][query] = alpha * O^T + sum_key V[key][c] * P^T[key][query]   (x 2^15)
+        // (the rescale is skipped when no query of the wave raised its running max: alpha == 1
+        // exactly, the common case once the first tiles have been seen)
+        const bool rescale = __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
+            if (rescale) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[c][i] *= alpha;
+                for (int i = 0; i < 16; ++i) oacc[c][i] *= alpha;
+            }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const ah8 vhi = *reinterpret_cast<const ah8*>(Vh + (c * 32 + qi) * VROW + (16 * s2 + 8 * half) * 2);
