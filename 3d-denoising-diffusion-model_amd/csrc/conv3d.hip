@@ -8,11 +8,16 @@
 //   A operand      input halo tile [voxel][16 ci] staged ONCE per ci-chunk in
 //                  LDS (already normalised+activated), read per tap at a
 //                  constant LDS offset (ds_read_b128)
-//   B operand      packed weights streamed L2 -> VGPR (global_load_dwordx4),
-//                  private to the wave's 32 couts, prefetched one tap ahead
+//   B operand      packed weights streamed L2 -> VGPR (buffer_load_dwordx4),
+//                  private to the wave's 32 couts, 3-tap register ring
 //   split-K        blockIdx.z owns a range of the ci-chunks (low-res levels)
 //
-// Two arithmetic modes (template PREC), same fp32 inputs, outputs and
+// This file: the direct form (all shapes and input modes), the split-K reduce and the
+// dispatcher.  The 3x3x3 layers that carry the network's FLOPs run the Winograd-along-depth
+// forms instead: conv3d_wz.h (two workgroups per CU), conv3d_wzs.h (wave-specialised,
+// persistent; the 64^3 level and the f16 mode), conv3d_wz2.h / conv3d_db.h (measured experiments).
+//
+// Arithmetic modes (template PREC), same fp32 inputs, outputs and
 // accumulators:
 //   PREC 0  v_mfma_f32_32x32x2_f32: exact fp32 products (bitwise an fmaf chain),
 //           64 FLOP/clk/SIMD.
@@ -22,6 +27,8 @@
 //           v_mfma_f32_32x32x16_f16 (every f16 x f16 product is exact in fp32).
 //           Operand representation error ~2^-23 relative -- below the fp32
 //           accumulation error both modes share -- at 16/3 the MFMA rate.
+//   PREC 2  one product on the hi halves only (operands rounded to f16): the reference's
+//           --use_fp16 analogue.
 //
 // K order inside a channel block is permuted in PREC 0 (lane half h supplies
 // channel 4h+s at step s) so both operands are 16-byte loads; the weight packer
