@@ -49,18 +49,37 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
         constexpr int TZ = WM * MT * 32 / (TX * TY);
         const bool split = p.ksplit > 1;
         const bool full = z0 + TZ <= p.D && y0 + TY <= p.H && x0 + TX <= p.W;
-        if (full && p.out_layout == DDPM3D_OUT_NDHWC &&
-            (split || p.res_mode == DDPM3D_RES_NONE || p.res_mode == DDPM3D_RES_SAME)) {
+        // residual of a split conv is the reduce kernel's business
+        const int rm = split ? DDPM3D_RES_NONE : p.res_mode;
+        // the residual tensor of the up / down ResBlocks is the block input at the other
+        // resolution (H/2 x W/2 or 2H x 2W); its sample must be 32-bit addressable too
+        const size_t Hr = rm == DDPM3D_RES_UP ? p.H / 2 : (rm == DDPM3D_RES_POOL ? (size_t)p.H * 2 : p.H);
+        const size_t Wr = rm == DDPM3D_RES_UP ? p.W / 2 : (rm == DDPM3D_RES_POOL ? (size_t)p.W * 2 : p.W);
+        const size_t samp_r = (size_t)p.D * Hr * Wr * p.Cout;
+        if (full && p.out_layout == DDPM3D_OUT_NDHWC && samp_r * 4 < 0xFFFFFFF0ull) {
             const size_t samp = DHW * p.Cout;                       // elements per sample (< 2^30, C ABI guard)
             const unsigned cstride = (unsigned)p.Cout * 4;          // bytes per voxel
             float* dst = split ? p.partial + ((size_t)ksplit_idx * p.N + n) * samp : p.out + (size_t)n * samp;
             const __amdgpu_buffer_rsrc_t drsrc = make_rsrc(dst, (unsigned)(samp * 4));
-            const bool resid = !split && p.res_mode == DDPM3D_RES_SAME;
-            const __amdgpu_buffer_rsrc_t rrsrc = make_rsrc(resid ? p.res + (size_t)n * samp : dst, (unsigned)(samp * 4));
+            const bool resid = rm != DDPM3D_RES_NONE;
+            const __amdgpu_buffer_rsrc_t rrsrc =
+                make_rsrc(resid ? p.res + (size_t)n * samp_r : dst, (unsigned)((resid ? samp_r : samp) * 4));
             // the lane's half adds 4 to the MFMA row: 4 voxels in x (8-wide tile) or one row in y (4-wide)
             const unsigned hx = (4 * half) & (TX - 1), hy = ((4 * half) >> TXL) & (TY - 1);
             const unsigned vbase = (((unsigned)z0 * p.H + y0 + hy) * p.W + x0 + hx) * cstride + (unsigned)cout * 4;
             const unsigned voff = cvalid ? vbase : DDPM3D_OOB_OFFSET;   // out-of-range lanes: loads 0, stores dropped
+            // Residual addressing, also "lane base + wave-uniform offset" (tiles start at even y0, x0):
+            //   SAME  x[z][y][x]                      : the output's own offsets
+            //   UP    x[z][y>>1][x>>1] (unet.py:241)  : (t0 + h) >> 1 = (t0 >> 1) + (h >> 1) -- the half's
+            //         4 voxels in x are 2 source voxels; in a 4-wide tile its one row in y shares the source row
+            //   POOL  mean of x[z][2y+{0,1}][2x+{0,1}]: doubled offsets, four loads
+            const unsigned rW = (unsigned)Wr, rH = (unsigned)Hr;
+            unsigned rbase = vbase;
+            if (rm == DDPM3D_RES_UP)
+                rbase = (((unsigned)z0 * rH + (y0 >> 1)) * rW + (x0 >> 1) + (hx >> 1)) * cstride + (unsigned)cout * 4;
+            else if (rm == DDPM3D_RES_POOL)
+                rbase = (((unsigned)z0 * rH + 2 * (y0 + hy)) * rW + 2 * (x0 + hx)) * cstride + (unsigned)cout * 4;
+            const unsigned roff = cvalid ? rbase : DDPM3D_OOB_OFFSET;
             const float bias = (!split && cvalid) ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
             float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -73,10 +92,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                     soff[reg] = (unsigned)((tz * p.H + ty) * p.W + tx) * cstride;
                 }
                 float r[16];
-                if (resid) {
+                if (rm == DDPM3D_RES_SAME) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg)
-                        r[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, voff, soff[reg], 0));
+                        r[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, soff[reg], 0));
+                } else if (rm == DDPM3D_RES_UP) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
+                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
+                        const unsigned so = (unsigned)((tz * rH + (ty >> 1)) * rW + (tx >> 1)) * cstride;
+                        r[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, so, 0));
+                    }
+                } else if (rm == DDPM3D_RES_POOL) {
+                    // AvgPool3d window order (h, w): ((r00 + r01) + r10) + r11, then * 1/4 (ddpm3d_residual)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
+                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
+                        const unsigned so = (unsigned)((tz * rH + 2 * ty) * rW + 2 * tx) * cstride;
+                        const float r00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, so, 0));
+                        const float r01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, so + cstride, 0));
+                        const float r10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, so + rW * cstride, 0));
+                        const float r11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, so + (rW + 1) * cstride, 0));
+                        r[reg] = (((r00 + r01) + r10) + r11) * 0.25f;
+                    }
                 }
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
