@@ -122,7 +122,7 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     k.tilesZ = c.tilesZ; k.tilesY = c.tilesY; k.tilesX = c.tilesX;
     k.stats_rows = c.stats_rows;
     k.reduce_vox = c.reduce_vox;
-    k.ztiles = 1;
+    k.hint = d->kernel_hint;
     k.ksplit = c.S;
     k.chunks_per_split = (k.CinPad / DDPM3D_CONV_CK + c.S - 1) / c.S;
     k.partial = (float*)d->workspace;
@@ -140,9 +140,9 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
             return fail(DDPM3D_EINVAL, "conv3d: one output sample exceeds 4 GiB; tile the volume");
         k.src0_bytes = (unsigned)b0; k.src1_bytes = (unsigned)b1; k.w_bytes = (unsigned)wb;
         // workgroup -> XCD order: keep on one XCD whichever operand is the larger stream
-        // (DDPM3D_WSTAT=0/1 forces it, for A/B runs)
-        static const int force = [] { const char* e = getenv("DDPM3D_WSTAT"); return e ? atoi(e) : -1; }();
-        k.wstat = force >= 0 ? force : ((long long)wb > b0 + b1 ? 1 : 0);
+        k.wstat = (d->kernel_hint & DDPM3D_HINT_WSTAT_ON)    ? 1
+                  : (d->kernel_hint & DDPM3D_HINT_WSTAT_OFF) ? 0
+                                                             : ((long long)wb > b0 + b1 ? 1 : 0);
     }
     if (c.PREC != DDPM3D_PREC_F32)  // output scales sit behind the f16 image
         k.wscale = (const float*)((const char*)d->w_packed +

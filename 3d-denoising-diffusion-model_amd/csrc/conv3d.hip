@@ -14,8 +14,7 @@
 //
 // This file: the direct form (all shapes and input modes), the split-K reduce and the
 // dispatcher.  The 3x3x3 layers that carry the network's FLOPs run the Winograd-along-depth
-// forms instead: conv3d_wz.h (two workgroups per CU), conv3d_wzs.h (wave-specialised,
-// persistent; the 64^3 level and the f16 mode), conv3d_wz2.h / conv3d_db.h (measured experiments).
+// form instead (conv3d_wz.h, staging in conv3d_stage.h).
 //
 // Arithmetic modes (template PREC), same fp32 inputs, outputs and
 // accumulators:
@@ -35,15 +34,14 @@
 // (ops.hip) stores the order each mode reads.
 #include <hip/hip_runtime.h>
 #include "conv3d_load.h"
-#include "conv3d_db.h"  // LdsGeom, conv_epilogue, and the double-buffered 3x3x3 variant
+#include "conv3d_epilogue.h"  // LdsGeom, conv_epilogue
 
 // PIPE = 1: IN_SAME / IN_UP inputs, staging software-pipelined; PIPE = 0: IN_POOL / IN_PLANAR2.
 template <int PREC, int PIPE, int KS, int WN, int MT, int TXL, int TYL>
-__global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_kernel(const ConvK p) {
+__global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const ConvK p) {
     constexpr int CK = DDPM3D_CONV_CK;
     constexpr int WM = 4 / WN;
-    // MT = 32-row accumulators per wave; workgroup tile = WM * MT * 32 voxels
-    // (128, or 256 on the full-resolution level: half the weight traffic and barriers per MFMA)
+    // MT = 32-row accumulators per wave; workgroup tile = WM * MT * 32 voxels = 128
     constexpr int TX = 1 << TXL, TY = 1 << TYL;
     constexpr int TZ = WM * MT * 32 / (TX * TY);
     constexpr int PAD = KS / 2;
@@ -158,9 +156,6 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         __syncthreads();  // everyone done reading the previous chunk's tile
         // ------------------------------------------------ stage the halo tile
-#ifdef DDPM3D_ABL_NO_RESTAGE  // (timing experiments only: stage the first chunk, then reuse it)
-        if (chunk == chunk_begin)
-#endif
         {
             auto store_item = [&](int hz, int hy, int hx, const f32x4 v) {
                 unsigned char* vrow = lds + (hz * RZ + hy * RY + hx * VS) * 16;
@@ -229,21 +224,15 @@ __global__ __launch_bounds__(256, ((MT >= 8 || TXL == 2) ? 2 : 3)) void conv3d_k
         }
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
-#ifndef DDPM3D_ABL_NO_BSTREAM  // (timing experiments only: reuse the first taps' weights)
             if (tap + 2 < NT) {
                 bq[(tap + 2) % 3][0] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride);
                 if (LO) bq[(tap + 2) % 3][1] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride + wpart);
             }
-#endif
             // all of this chunk's weight loads are in flight: now the next chunk's halo loads
             if (PIPE && tap == (NT >= 3 ? NT - 3 : 0) && more) issue_raw(hs);
             const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
             const int tapoff = (dz * RZ + dy * RY + dx * VS) * 16;
-#ifdef DDPM3D_ABL_NO_BSTREAM
-            const u32x4 b0 = bq[tap % 2][0], b1 = LO ? bq[tap % 2][1] : b0;
-#else
             const u32x4 b0 = bq[tap % 3][0], b1 = LO ? bq[tap % 3][1] : b0;
-#endif
             if constexpr (PREC == 0) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -438,79 +427,20 @@ hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) 
 #endif  // DDPM3D_PREC_ONLY == 0
 
 #if DDPM3D_PREC_ONLY == 1
-// Winograd-D form of the f16x3 3x3x3 conv (eligibility is checked by the C ABI)
+// Winograd-D form of the f16x3 / f16 3x3x3 conv (eligibility is checked by the C ABI)
 #include "conv3d_wz.h"
-#include "conv3d_wz2.h"
-#include "conv3d_wzs.h"
 hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t st) {
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     const int gy = k.CoutPad / 128;
-    constexpr size_t lds = (size_t)4 * LdsGeom<8, 10, 10>::RZ * 16;
-    // Experiment, opt-in: 8x8x4-voxel tiles, one wave per SIMD (conv3d_wz2.h).  DDPM3D_WZ2=1
-    // always (when D % 4 == 0), -1 for long reductions only (>= 16 chunks per workgroup, which
-    // amortise a lone workgroup's un-overlapped prologue and epilogue).  It ties the default
-    // kernel within 1-2 % (r01), so the default stays the simpler one.
-    static const int wz2 = [] { const char* e = getenv("DDPM3D_WZ2"); return e ? atoi(e) : 0; }();
-    const bool f16 = c.PREC == DDPM3D_PREC_F16_WZ;   // one MFMA per product: wave-specialised kernel only
-    if (!f16 && k.D % 4 == 0 && (wz2 > 0 || (wz2 < 0 && k.chunks_per_split >= 16))) {
-        static const hipError_t attr =
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wz2_kernel<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * lds));
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(conv3d_wz2_kernel<4>, dim3(gx / 2, gy, k.ksplit), dim3(256), 4 * lds, st, k);
-        return hipGetLastError();
-    }
-    // wave-specialised form (conv3d_wzs.h): 512 threads, waves 0-3 compute, 4-7 stage
-    // DDPM3D_WZS: 0 never, 1 / 2 always (weight ring of 4 / 6 taps: 24 / 40 KB of weight loads in
-    // flight per CU -- no difference, 0.464 vs 0.471 ms, so latency x bytes-in-flight is not what
-    // caps the weight stream; A operands two taps ahead made none either); unset: on the big grids,
-    // where it measured 2-3 % faster than the kernel below (r01: 0.463 / 0.874 vs 0.472 / 0.892 ms
-    // on 128->128 / 256->128 @ 64^3) -- on the small levels its lone workgroup per CU loses 3-7 %
-    static const int wzs_env = [] { const char* e = getenv("DDPM3D_WZS"); return e ? atoi(e) : -1; }();
-    // The f16 form (one MFMA per product, 64 cycles of MFMA per tap) gets a 9-tap weight ring and
-    // A operands 3 taps ahead (~510 / ~190 cycles of cover; 12 / 5 spilled 84 bytes).
-    const int wzs = f16 ? 3 : (wzs_env >= 0 ? wzs_env : ((long long)gx * gy * k.ksplit >= 2048 ? 1 : 0));
-    if (wzs != 0) {
-        const void* fn = wzs == 1   ? reinterpret_cast<const void*>(&conv3d_wzs_kernel<4, 1, true>)
-                         : wzs == 2 ? reinterpret_cast<const void*>(&conv3d_wzs_kernel<6, 1, true>)
-                                    : reinterpret_cast<const void*>(&conv3d_wzs_kernel<9, 3, false>);
-        static hipError_t attrs[3] = {hipErrorUnknown, hipErrorUnknown, hipErrorUnknown};
-        hipError_t& attr = attrs[wzs == 1 ? 0 : (wzs == 2 ? 1 : 2)];
-        if (attr == hipErrorUnknown)
-            attr = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
-        if (attr != hipSuccess) return attr;
-        // z-pairs per workgroup: as many as still leave every CU two workgroups (balance)
-        static const int zt_force = [] { const char* e = getenv("DDPM3D_WZS_ZT"); return e ? atoi(e) : 0; }();
-        ConvK k2 = k;
-        k2.ztiles = 1;
-        if (zt_force > 0) {
-            k2.ztiles = zt_force < k.tilesZ ? zt_force : k.tilesZ;
-        } else {
-            while (k2.ztiles * 2 <= k.tilesZ && k2.ztiles < 8 &&
-                   (long long)gx * gy * k.ksplit / (k2.ztiles * 2) >= 512)
-                k2.ztiles *= 2;
-        }
-        const int zgroups = (k.tilesZ + k2.ztiles - 1) / k2.ztiles;
-        const int gxs = k.N * zgroups * k.tilesY * k.tilesX;
-        if (wzs == 1)
-            hipLaunchKernelGGL((conv3d_wzs_kernel<4, 1, true>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
-        else if (wzs == 2)
-            hipLaunchKernelGGL((conv3d_wzs_kernel<6, 1, true>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
-        else
-            hipLaunchKernelGGL((conv3d_wzs_kernel<9, 3, false>), dim3(gxs, gy, k.ksplit), dim3(512), 2 * lds, st, k2);
-        return hipGetLastError();
-    }
-    // DDPM3D_WZ_DB=1 selects the double-buffered variant (one barrier per chunk, staging spread
-    // over the taps): 3-5 % slower than the single-image kernel with two workgroups per CU (r01)
-    static const bool db = [] { const char* e = getenv("DDPM3D_WZ_DB"); return e && atoi(e) != 0; }();
-    if (db) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wz_kernel<1>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
-        if (attr != hipSuccess) return attr;
-        hipLaunchKernelGGL(conv3d_wz_kernel<1>, dim3(gx, gy, k.ksplit), dim3(256), 2 * lds, st, k);
-    } else {
-        hipLaunchKernelGGL(conv3d_wz_kernel<0>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
-    }
+    constexpr size_t lds = (size_t)WzGeom::BUF;
+    // One kernel form.  Measured and dropped in r02 (profiles/r02_layer_ab_*.txt): a
+    // wave-specialised persistent form (compute waves + loader waves, tile walk, epilogue hand-off
+    // through LDS) and a 128-row wave tile with one wave per SIMD -- both 3-15 % behind this one
+    // once the staging was cut to ~330 instructions per item (conv3d_stage.h).
+    if (c.PREC == DDPM3D_PREC_F16_WZ)
+        hipLaunchKernelGGL(conv3d_wz_kernel<false>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+    else
+        hipLaunchKernelGGL(conv3d_wz_kernel<true>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     return hipGetLastError();
 }
 #endif
@@ -533,48 +463,15 @@ hipError_t DDPM3D_CAT(ddpm3d_launch_conv_p, DDPM3D_PREC_ONLY)(const ConvK& k, co
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     const int gy = (k.CoutPad + 32 * c.WN - 1) / (32 * c.WN);
     const int pipe = (k.in_mode == DDPM3D_IN_SAME || k.in_mode == DDPM3D_IN_UP) ? 1 : 0;
-    // Double-buffered variant (conv3d_db.h): 3x3x3, 128x128 tile, pipelined input, every wave
-    // active.  OPT-IN (DDPM3D_DBUF=1): measured on MI355X it is 0-4 % SLOWER than the
-    // single-buffer kernel (128->128 @ 64^3, f16x3: 331 vs 344 TFLOP/s) -- with three
-    // single-buffer workgroups per CU the staging phase is already hidden by the neighbours,
-    // and the second LDS image costs one resident workgroup.
-    {
-        static const bool dbuf_on = [] { const char* e = getenv("DDPM3D_DBUF"); return e && atoi(e) != 0; }();
-        if (dbuf_on && pipe && c.KS == 3 && c.WN == 4 && c.MT == 4 && k.CoutPad % 128 == 0) {
-            constexpr int P = DDPM3D_PREC_ONLY;
-            // two halo images = 71 680 B of dynamic LDS: above the 64 KiB default, so raise the cap once
-            if (c.TXL == 3) {
-                constexpr size_t lds = 2 * (size_t)4 * LdsGeom<8, 10, 10>::RZ * 16;
-                static const hipError_t attr = hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(&conv3d_db_kernel<P, 3, 3>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (attr != hipSuccess) return attr;
-                hipLaunchKernelGGL((conv3d_db_kernel<P, 3, 3>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
-            } else {
-                constexpr size_t lds = 2 * (size_t)10 * LdsGeom<4, 6, 6>::RZ * 16;
-                static const hipError_t attr = hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(&conv3d_db_kernel<P, 2, 2>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (attr != hipSuccess) return attr;
-                hipLaunchKernelGGL((conv3d_db_kernel<P, 2, 2>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
-            }
-            return hipGetLastError();
-        }
-    }
 #define CASE(P_, PI_, KS_, WN_, MT_, TXL_, TYL_)                                                      \
     if (pipe == PI_ && c.KS == KS_ && c.WN == WN_ && c.MT == MT_ && c.TXL == TXL_ && c.TYL == TYL_)   \
         return launch_cfg<P_, PI_, KS_, WN_, MT_, TXL_, TYL_>(k, gx, gy, st);
 #define CASES(P_, PI_)                                                                          \
-    CASE(P_, PI_, 3, 4, 8, 3, 3)                                                                \
     CASE(P_, PI_, 3, 4, 4, 3, 3) CASE(P_, PI_, 3, 2, 2, 3, 3) CASE(P_, PI_, 3, 1, 1, 3, 3)      \
     CASE(P_, PI_, 3, 4, 4, 2, 2) CASE(P_, PI_, 3, 2, 2, 2, 2) CASE(P_, PI_, 3, 1, 1, 2, 2)      \
     CASE(P_, PI_, 1, 4, 4, 3, 3) CASE(P_, PI_, 1, 2, 2, 3, 3) CASE(P_, PI_, 1, 1, 1, 3, 3)      \
     CASE(P_, PI_, 1, 4, 4, 2, 2) CASE(P_, PI_, 1, 2, 2, 2, 2) CASE(P_, PI_, 1, 1, 1, 2, 2)
-#ifdef DDPM3D_ONLY_ONE  // (compile-time experiments: a single instantiation)
-    CASE(DDPM3D_PREC_ONLY, 1, 3, 4, 4, 3, 3)
-#else
     CASES(DDPM3D_PREC_ONLY, 1) CASES(DDPM3D_PREC_ONLY, 0)
-#endif
 #undef CASES
 #undef CASE
     return hipErrorInvalidValue;

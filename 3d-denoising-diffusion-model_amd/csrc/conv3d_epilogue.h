@@ -1,15 +1,6 @@
-// Double-buffered variant of the 3x3x3 conv kernel (see conv3d.hip for the common design)
-// for the shapes that carry the network's FLOPs: pipelined inputs (IN_SAME / IN_UP), a
-// 128-voxel x 128-cout tile, every wave active (CoutPad % 128 == 0).
-//
-// The single-buffer kernel has, per 16-channel chunk, barrier -> staging (affine + SiLU +
-// f16 split + LDS stores, ~500 VALU per thread) -> barrier -> 27 taps of MFMA; during the
-// staging phase this workgroup's matrix pipes idle and only the other resident workgroups
-// cover it.  Here the LDS holds two halo images: while the taps of chunk c read image c&1,
-// the staging of chunk c+1 is spread over the tap loop (one item after every third tap, VALU
-// and LDS stores co-issuing with the MFMAs of the same wave) into image (c+1)&1, and the raw
-// loads of chunk c+2 are issued at tap 24, after the chunk's last weight loads (vmcnt retires
-// in order).  One barrier per chunk.
+// Pieces shared by every conv kernel: the operand vector types, the LDS geometry of the halo
+// image and the epilogue (bias / residual / store / GroupNorm partial sums, or the raw split-K
+// slab).
 #pragma once
 #include "conv3d_load.h"
 
@@ -195,193 +186,4 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
             *reinterpret_cast<float2*>(p.stats + (((size_t)n * p.Cout + cout) * p.stats_rows + row) * 2) = v2;
         }
     }
-}
-
-template <int PREC, int TXL, int TYL>
-__global__ __launch_bounds__(256, 2) void conv3d_db_kernel(const ConvK p) {
-    constexpr int CK = DDPM3D_CONV_CK, MT = 4, NT = 27, PAD = 1;
-    constexpr int TX = 1 << TXL, TY = 1 << TYL, TZ = 128 / (TX * TY);
-    constexpr int HX = TX + 2, HY = TY + 2, HZ = TZ + 2;
-    constexpr int HV = HX * HY * HZ;
-    constexpr int VS = 5;
-    constexpr int RY = LdsGeom<TX, HX, HY>::RY;
-    constexpr int RZ = LdsGeom<TX, HX, HY>::RZ;
-    constexpr int BUF = HZ * RZ * 16;                 // bytes of one halo image
-    constexpr int QPV = CK / 4;
-    constexpr int NL = (HV * QPV + 255) / 256;        // staging items per thread
-    static_assert(1 + 3 * (NL - 1) < NT - 3, "staging must finish before the next raw loads are issued");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);   // 4 waves along Cout
-    const int half = lane >> 5;
-
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tx_i = tile % p.tilesX; tile /= p.tilesX;
-    const int ty_i = tile % p.tilesY; tile /= p.tilesY;
-    const int tz_i = tile % p.tilesZ; tile /= p.tilesZ;
-    const int n = tile;
-    const int x0 = tx_i * TX, y0 = ty_i * TY, z0 = tz_i * TZ;
-
-    int arow[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const int m = t * 32 + (lane & 31);
-        const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
-        arow[t] = (tz * RZ + ty * RY + tx * VS + half) * 16;
-    }
-
-    const int cout = blockIdx.y * 128 + wn * 32 + (lane & 31);
-    const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.w_bytes);
-    const unsigned wlane = ((unsigned)cout * 2 + half) * 16;
-    const unsigned wpart = (unsigned)p.CoutPad * 32;
-    const unsigned wchunk_stride = 2 * wpart;
-    const unsigned wtap_stride = (unsigned)(p.CinPad / CK) * wchunk_stride;
-
-    f32x16 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-
-    const int nchunks = p.CinPad / CK;
-    const int chunk_begin = blockIdx.z * p.chunks_per_split;
-    const int chunk_end = min(nchunks, chunk_begin + p.chunks_per_split);
-
-    const int q = tid % QPV;
-    const int up_shift = p.in_mode == DDPM3D_IN_UP ? 1 : 0;
-    const unsigned act_mask = p.act ? 0xFFFFFFFFu : 0u;
-    f32x4 raw[NL];
-    int vox[NL];
-    HaloSrc hs = halo_src<CK>(p, n, chunk_begin < chunk_end ? chunk_begin : 0, q);
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int idx = tid + i * 256;
-        const int hv = idx / QPV;
-        const int hz = hv / (HY * HX);
-        const int rem = hv - hz * (HY * HX);
-        const int hy = rem / HX;
-        const int hx = rem - hy * HX;
-        vox[i] = idx < HV * QPV ? halo_vox(p, n, z0 - PAD + hz, y0 - PAD + hy, x0 - PAD + hx, hs.Hs, hs.Ws, up_shift)
-                                : -1;
-    }
-    auto issue_raw = [&](const HaloSrc& h) {
-        const __amdgpu_buffer_rsrc_t srsrc = make_rsrc(h.src, h.src_bytes);
-        const unsigned row_bytes = (unsigned)h.Cs * 4, soff = (unsigned)h.cb * 4;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            const unsigned voff = vox[i] < 0 ? DDPM3D_OOB_OFFSET : (unsigned)vox[i] * row_bytes + q * 16;
-            raw[i] = __builtin_bit_cast(f32x4, buffer_load16(srsrc, voff, soff));
-        }
-    };
-    // affine + activation + (split) + store of staging item i into the image at `buf`
-    auto finish_item = [&](const int i, unsigned char* buf) {
-        const int idx = tid + i * 256;
-        if (idx < HV * QPV) {
-            const int hv = idx / QPV;
-            const int hz = hv / (HY * HX);
-            const int rem = hv - hz * (HY * HX);
-            const int hy = rem / HX;
-            const int hx = rem - hy * HX;
-            const f32x4 v = halo_finish<PREC != 0>(hs, raw[i], vox[i] >= 0, act_mask);
-            unsigned char* vrow = buf + (hz * RZ + hy * RY + hx * VS) * 16;
-            if constexpr (PREC == 0) {
-                *reinterpret_cast<f32x4*>(vrow + q * 16) = v;
-            } else {
-                h4 hi, lo;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float s = fminf(fmaxf(v[c] * DDPM3D_X3_ACT_SCALE, -60000.0f), 60000.0f);
-                    hi[c] = (_Float16)s;
-                    lo[c] = (_Float16)(s - (float)hi[c]);
-                }
-                *reinterpret_cast<h4*>(vrow + q * 8) = hi;
-                if constexpr (PREC == 1) *reinterpret_cast<h4*>(vrow + 32 + q * 8) = lo;
-            }
-        }
-    };
-
-    // prologue: image 0 <- first chunk; raw <- second chunk
-    if (chunk_begin < chunk_end) {
-        issue_raw(hs);
-#pragma unroll
-        for (int i = 0; i < NL; ++i) finish_item(i, lds);
-        if (chunk_begin + 1 < chunk_end) {
-            hs = halo_src<CK>(p, n, chunk_begin + 1, q);
-            issue_raw(hs);
-        }
-    }
-    __syncthreads();
-
-    constexpr bool LO = PREC != 2;
-    int par = 0;
-    for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
-        const bool more = chunk + 1 < chunk_end, more2 = chunk + 2 < chunk_end;
-        const unsigned char* bufc = lds + par * BUF;
-        unsigned char* bufn = lds + (par ^ 1) * BUF;
-        const unsigned wchunk = (unsigned)chunk * wchunk_stride;
-        u32x4 bq[3][2];
-        bq[0][0] = buffer_load16(wrsrc, wlane, wchunk);
-        if (LO) bq[0][1] = buffer_load16(wrsrc, wlane, wchunk + wpart);
-        bq[1][0] = buffer_load16(wrsrc, wlane, wchunk + wtap_stride);
-        if (LO) bq[1][1] = buffer_load16(wrsrc, wlane, wchunk + wtap_stride + wpart);
-#pragma unroll
-        for (int tap = 0; tap < NT; ++tap) {
-            if (tap + 2 < NT) {
-                bq[(tap + 2) % 3][0] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride);
-                if (LO) bq[(tap + 2) % 3][1] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride + wpart);
-            }
-            // staging of chunk+1, one item after every third tap (raw[] was loaded during the
-            // previous chunk's last taps, hs holds chunk+1's affine quad)
-            if ((tap % 3) == 1 && (tap / 3) < NL && more) finish_item(tap / 3, bufn);
-            // all of this chunk's weight loads are in flight and raw[] is consumed: chunk+2's loads
-            if (tap == NT - 3 && more2) {
-                hs = halo_src<CK>(p, n, chunk + 2, q);
-                issue_raw(hs);
-            }
-            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            const int tapoff = (dz * RZ + dy * RY + dx * VS) * 16;
-            const u32x4 b0 = bq[tap % 3][0], b1 = LO ? bq[tap % 3][1] : b0;
-            if constexpr (PREC == 0) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    f32x4 a[MT];
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-                        a[t] = *reinterpret_cast<const f32x4*>(bufc + arow[t] + tapoff + kk * 32);
-                    const f32x4 b = __builtin_bit_cast(f32x4, kk == 0 ? b0 : b1);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-#pragma unroll
-                        for (int t = 0; t < MT; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], b[s], acc[t], 0, 0, 0);
-                }
-            } else if constexpr (PREC == 2) {
-                const h8 bhi = __builtin_bit_cast(h8, b0);
-#pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const h8 ahi = *reinterpret_cast<const h8*>(bufc + arow[t] + tapoff);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[t], 0, 0, 0);
-                }
-            } else {
-                const h8 bhi = __builtin_bit_cast(h8, b0);
-                const h8 blo = __builtin_bit_cast(h8, b1);
-#pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const h8 ahi = *reinterpret_cast<const h8*>(bufc + arow[t] + tapoff);
-                    const h8 alo = *reinterpret_cast<const h8*>(bufc + arow[t] + tapoff + 32);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[t], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();  // image (par^1) complete, image par free for chunk+2's staging
-        par ^= 1;
-    }
-
-    const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<PREC, 1, MT, TXL, TYL>(p, acc, n, z0, y0, x0, tile_in_n, 0, cout, half, blockIdx.z);
 }

@@ -34,7 +34,7 @@ struct ConvK {
     int ksplit, chunks_per_split;
     int wstat;  // weight-stationary workgroup -> XCD order (conv3d_load.h wg_id)
     int reduce_vox;  // voxels per statistics row of the split-K reduce
-    int ztiles;      // conv3d_wzs_kernel: consecutive z-pairs one workgroup walks
+    int hint;        // ddpm3d_conv_desc.kernel_hint
 };
 
 struct ConvCfg {
@@ -69,14 +69,7 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
     c.KS = ksize;
     c.WN = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
     if (H >= 8 && W >= 8) { c.TXL = 3; c.TYL = 3; } else { c.TXL = 2; c.TYL = 2; }
-    c.MT = c.WN;  // 128-voxel tile
-    {
-        // A 256-voxel tile (8 accumulators per wave) halves the weight stream and the barriers
-        // per MFMA, but as compiled today (2 waves/SIMD, 254 VGPRs) it measured 2.2x SLOWER than
-        // the 128-voxel tile on the 64^3 level (159 vs 353 TFLOP/s): opt-in for experiments only.
-        const char* force = getenv("DDPM3D_MT8");
-        if (c.WN == 4 && c.TXL == 3 && ksize == 3 && force && atoi(force) != 0) c.MT = 8;
-    }
+    c.MT = c.WN;  // 128-voxel tile (a 256-voxel tile, 8 accumulators per wave, measured 2.2x slower: r01)
     const int TX = 1 << c.TXL, TY = 1 << c.TYL, TZ = (4 / c.WN) * c.MT * 32 / (TX * TY);
     c.tilesX = (W + TX - 1) / TX;
     c.tilesY = (H + TY - 1) / TY;
@@ -90,39 +83,25 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
         // exposed halo load, ~1 us) and the split pays when few workgroups each walk many
         // chunks.  Units ~us: chunk 1, prologue + epilogue 3, the reduce launch 10.  Measured
         // before (r01): 1024->512 @ 64x4x4 took 71 us on 32 workgroups x 64 chunks.
-        const char* force = getenv("DDPM3D_KSPLIT1");
-        if (force) {
-            best = atoi(force);
-            if (best < 1) best = 1;
-            if (best > nch) best = nch;
-        } else {
-            double best_cost = 1e300;
-            for (int s = 1; s <= 32 && s <= nch; ++s) {
-                const int cps = (nch + s - 1) / s;
-                if (s > 1 && cps < 4) break;
-                const long long per_cu = (blocks * s + 255) / 256;
-                const double cost = (double)per_cu * (cps + 3.0) + (s > 1 ? 10.0 : 0.0);
-                if (cost < best_cost * 0.9) { best_cost = cost; best = s; }
-            }
+        double best_cost = 1e300;
+        for (int s = 1; s <= 32 && s <= nch; ++s) {
+            const int cps = (nch + s - 1) / s;
+            if (s > 1 && cps < 4) break;
+            const long long per_cu = (blocks * s + 255) / 256;
+            const double cost = (double)per_cu * (cps + 3.0) + (s > 1 ? 10.0 : 0.0);
+            if (cost < best_cost * 0.9) { best_cost = cost; best = s; }
         }
     }
     if (ksize == 3 && c.WN == 4) {
-        const char* force = getenv("DDPM3D_KSPLIT");
-        if (force) {
-            best = atoi(force);
-            if (best < 1) best = 1;
-            if (best > nch) best = nch;
-        } else {
-            static const double eff[4] = {1.0, 0.62, 0.78, 0.82};
-            double best_cost = 1e300;
-            for (int s = 1; s <= 32 && s <= nch; ++s) {
-                const int cps = (nch + s - 1) / s;
-                if (s > 1 && cps < 2) break;
-                const long long per_cu = (blocks * s + 255) / 256;
-                const double e = eff[per_cu > 3 ? 3 : (int)per_cu];
-                const double cost = (double)per_cu * (cps + (s > 1 ? 0.75 : 0.5)) / e;
-                if (cost < best_cost * 0.97) { best_cost = cost; best = s; }
-            }
+        static const double eff[4] = {1.0, 0.62, 0.78, 0.82};
+        double best_cost = 1e300;
+        for (int s = 1; s <= 32 && s <= nch; ++s) {
+            const int cps = (nch + s - 1) / s;
+            if (s > 1 && cps < 2) break;
+            const long long per_cu = (blocks * s + 255) / 256;
+            const double e = eff[per_cu > 3 ? 3 : (int)per_cu];
+            const double cost = (double)per_cu * (cps + (s > 1 ? 0.75 : 0.5)) / e;
+            if (cost < best_cost * 0.97) { best_cost = cost; best = s; }
         }
     }
     c.S = best;

@@ -1,0 +1,194 @@
+// Lean staging of one (8x8x2-output tile, 16-channel chunk) item of the Winograd-D convolutions:
+// raw input planes -> GroupNorm/FiLM affine -> SiLU -> F(2,3) input transform along depth ->
+// f16 hi/lo split -> LDS image.  Shared by conv3d_wz.h and conv3d_wzs.h.
+//
+// Why this file exists (r02, tools/wzs_stamps.py): in the wave-specialised kernel the LOADER waves
+// were the critical path -- 8.2k cycles of staging per item against 7.7k cycles of tap loop, the
+// compute waves parked at the item barrier for 19-35 % of their life.  A wave issues in order at
+// ~4-5 cycles per instruction of ANY kind, and the staging code as compiled was ~1000 VALU plus ~700
+// scalar / v_readlane instructions per item (integer division by the chunk count, 64-bit address
+// chains, spilled SGPRs, per-value selects, packed-f32 ops that cost 3x beside MFMAs).  Here it is
+// ~330 VALU and a dozen scalar instructions:
+//   * every per-lane address is a 32-bit offset computed ONCE; per item only four scalar plane
+//     offsets change (buffer loads: uniform descriptor + lane offset + scalar offset);
+//   * out-of-volume (y, x) lanes never store: their LDS slots are zeroed once per workgroup (the
+//     tile column, hence the set of such lanes, is fixed); out-of-volume PLANES are a uniform skip;
+//   * "no activation" is exp2(-126) = 0 in the sigmoid's denominator instead of a per-value select;
+//   * the x8 pre-split scale is folded into the affine (exact: a power of two);
+//   * hi = cvt_pk(s), lo = cvt_pk(fma_mix(-hi + s)): 2 instructions per value instead of ~6;
+//   * scalar float code throughout (no f32x4 arithmetic: it lowers to v_pk_*_f32).
+// Value for value the arithmetic is the one of r01's staging (same roundings in the same order), so
+// the kernels stay bit-identical to each other and to the committed goldens' tolerances.
+#pragma once
+#include "conv3d_epilogue.h"
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 -> packed f16 hi (RNE) and packed f16 lo = f16(s - hi); the subtraction is exact
+__device__ __forceinline__ void split_pair(float s0, float s1, unsigned& hi, unsigned& lo) {
+    float l0, l1;
+    asm("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
+        "v_fma_mix_f32 %1, %0, -1.0, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hi), "=&v"(l0), "=&v"(l1)
+        : "v"(s0), "v"(s1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(l0), "v"(l1));
+}
+
+// geometry of the 8x8x2 tile's LDS image (4 transformed planes of 10x10 voxels, 80 B per voxel)
+struct WzGeom {
+    static constexpr int CK = DDPM3D_CONV_CK;
+    static constexpr int HX = 10, HY = 10, NP = 4, VS = 5;
+    static constexpr int RY = LdsGeom<8, HX, HY>::RY;
+    static constexpr int RZ = LdsGeom<8, HX, HY>::RZ;
+    static constexpr int BUF = NP * RZ * 16;          // bytes of one image
+    static constexpr int HC = HX * HY * (CK / 4);     // staging slots: (y, x, channel quad)
+    static constexpr int NL = (HC + 255) / 256;       // slots per staging thread
+};
+
+// Per-thread, launch-invariant part of the staging (256 staging threads, thread = lt).
+struct StageLane {
+    unsigned vo0[WzGeom::NL], vo1[WzGeom::NL];   // byte offset of slot i's voxel at plane zb in src0 / src1
+    int lds[WzGeom::NL];                         // byte offset of slot i inside a plane of the image
+    bool ok[WzGeom::NL];                         // slot exists and its (y, x) lies inside the volume
+    unsigned plane0, plane1;                     // bytes per z-plane of src0 / src1
+    int zb;                                      // first source plane the offsets refer to
+    float km, ka;                                // sigmoid exponent = fma(y8, km, ka)
+    int q;
+};
+
+// zb = the lowest input plane any item of this workgroup reads (clamped to 0)
+__device__ __forceinline__ StageLane stage_lane(const ConvK& p, int lt, int n, int y0, int x0, int zb) {
+    StageLane s;
+    const int up = p.in_mode == DDPM3D_IN_UP ? 1 : 0;
+    const int Hs = p.H >> up, Ws = p.W >> up;
+    s.q = lt & 3;
+    s.zb = zb;
+    s.plane0 = (unsigned)(Hs * Ws) * (unsigned)p.C0 * 4u;
+    s.plane1 = (unsigned)(Hs * Ws) * (unsigned)p.C1 * 4u;
+    // act: e = exp2(-y log2e) with y8 = 8 y;  none: e = exp2(-126) ~ 1e-38, 1 + e == 1, y8 * 1 = y8
+    s.km = p.act ? -1.44269504088896341f / DDPM3D_X3_ACT_SCALE : 0.0f;
+    s.ka = p.act ? 0.0f : -126.0f;
+#pragma unroll
+    for (int i = 0; i < WzGeom::NL; ++i) {
+        const int idx = lt + i * 256;
+        const int hyx = idx >> 2;
+        const int hy = hyx / WzGeom::HX, hx = hyx - hy * WzGeom::HX;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        s.ok[i] = idx < WzGeom::HC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        const unsigned vox = (unsigned)(((n * p.D + zb) * Hs + (y >> up)) * Ws + (x >> up));
+        s.vo0[i] = s.ok[i] ? vox * (unsigned)p.C0 * 4u + s.q * 16u : DDPM3D_OOB_OFFSET;
+        s.vo1[i] = s.ok[i] ? vox * (unsigned)p.C1 * 4u + s.q * 16u : DDPM3D_OOB_OFFSET;
+        s.lds[i] = (hy * WzGeom::RY + hx * WzGeom::VS) * 16 + s.q * 8;
+    }
+    return s;
+}
+
+// Slots of halo voxels outside H x W are zero for every item: written once, never again.
+__device__ __forceinline__ void stage_zero_border(const StageLane& s, unsigned char* lds_images, int nimages, int lt) {
+#pragma unroll
+    for (int i = 0; i < WzGeom::NL; ++i) {
+        if (lt + i * 256 < WzGeom::HC && !s.ok[i]) {
+            for (int b = 0; b < nimages; ++b)
+#pragma unroll
+                for (int j = 0; j < WzGeom::NP; ++j) {
+                    unsigned char* v = lds_images + b * WzGeom::BUF + j * WzGeom::RZ * 16 + s.lds[i];
+                    *reinterpret_cast<u32x2*>(v) = u32x2{0u, 0u};
+                    *reinterpret_cast<u32x2*>(v + 32) = u32x2{0u, 0u};
+                }
+        }
+    }
+}
+
+// One item's raw data: the NPL = 2 * NZP + 2 input planes z0-1 .. z0+2*NZP of the thread's slots (NZP
+// consecutive z-pairs share their inner planes) + the chunk's affine.
+template <int NPL>
+struct StageRawT {
+    f32x4 v[WzGeom::NL][NPL];
+    f32x4 ga, gb;
+    unsigned zmask;   // bit k: plane z0 - 1 + k lies inside the volume (uniform)
+};
+typedef StageRawT<4> StageRaw;
+
+// issue the loads of item (first z-pair z0, channel chunk `chunk`)
+template <int NPL>
+__device__ __forceinline__ void stage_issue(const ConvK& p, const StageLane& s, StageRawT<NPL>& r, int n, int z0, int chunk) {
+    const int c0 = chunk * WzGeom::CK;
+    const bool from0 = c0 < p.C0;
+    const __amdgpu_buffer_rsrc_t rs = from0 ? make_rsrc(p.src0, p.src0_bytes) : make_rsrc(p.src1, p.src1_bytes);
+    const unsigned plane = from0 ? s.plane0 : s.plane1;
+    const unsigned cb4 = (unsigned)(from0 ? c0 : c0 - p.C0) * 4u;
+    r.zmask = 0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int z = z0 - 1 + k;
+        if ((unsigned)z < (unsigned)p.D) {
+            r.zmask |= 1u << k;
+            const unsigned soff = cb4 + (unsigned)(z - s.zb) * plane;
+#pragma unroll
+            for (int i = 0; i < WzGeom::NL; ++i)
+                r.v[i][k] = __builtin_bit_cast(f32x4, buffer_load16(rs, from0 ? s.vo0[i] : s.vo1[i], soff));
+        }
+    }
+    if (p.affA != nullptr) {
+        r.ga = *reinterpret_cast<const f32x4*>(p.affA + (size_t)n * p.Cin + c0 + s.q * 4);
+        r.gb = *reinterpret_cast<const f32x4*>(p.affB + (size_t)n * p.Cin + c0 + s.q * 4);
+    } else {
+        r.ga = f32x4{1.f, 1.f, 1.f, 1.f};
+        r.gb = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// raw -> image(s) at `buf` (z-pair zp at buf + zp * WzGeom::BUF).  X3 = false keeps only the hi
+// halves (f16 mode).
+template <bool X3, int NPL = 4>
+__device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<NPL>& r, unsigned char* buf) {
+    constexpr int NZP = (NPL - 2) / 2;
+    float sa[4], sb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        sa[c] = r.ga[c] * DDPM3D_X3_ACT_SCALE;
+        sb[c] = r.gb[c] * DDPM3D_X3_ACT_SCALE;
+    }
+#pragma unroll
+    for (int i = 0; i < WzGeom::NL; ++i) {
+        float d[NPL][4];   // 8 * act(A x + B) of the input planes
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            if (r.zmask & (1u << k)) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float y8 = __builtin_fmaf(r.v[i][k][c], sa[c], sb[c]);
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(y8, s.km, s.ka));
+                    d[k][c] = y8 * __builtin_amdgcn_rcpf(1.0f + e);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d[k][c] = 0.0f;
+            }
+        }
+        if (s.ok[i]) {
+#pragma unroll
+            for (int zp = 0; zp < NZP; ++zp)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int b = 2 * zp;
+                    float v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float t = j == 0 ? d[b][c] - d[b + 2][c]
+                                      : j == 1 ? d[b + 1][c] + d[b + 2][c]
+                                      : j == 2 ? d[b + 2][c] - d[b + 1][c]
+                                               : d[b + 1][c] - d[b + 3][c];
+                        v[c] = __builtin_amdgcn_fmed3f(t, -60000.0f, 60000.0f);
+                    }
+                    unsigned h0, h1, l0, l1;
+                    split_pair(v[0], v[1], h0, l0);
+                    split_pair(v[2], v[3], h1, l1);
+                    unsigned char* vrow = buf + zp * WzGeom::BUF + j * WzGeom::RZ * 16 + s.lds[i];
+                    *reinterpret_cast<u32x2*>(vrow) = u32x2{h0, h1};
+                    if (X3) *reinterpret_cast<u32x2*>(vrow + 32) = u32x2{l0, l1};
+                }
+        }
+    }
+}

@@ -25,7 +25,9 @@ PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X3_WZ, PREC_F16_WZ = 0, 1, 2, 3, 4
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16}
 # the Winograd-along-depth form of a mode (same arithmetic, 2/3 of the MFMAs), where one exists
 WINOGRAD_OF = {PREC_F16X3: PREC_F16X3_WZ, PREC_F16: PREC_F16_WZ}
-ABI_VERSION = 7
+ABI_VERSION = 8
+# ddpm3d_conv_desc.kernel_hint bits (launch orders of identical arithmetic; tests and A/B measurements)
+HINT_WSTAT_OFF, HINT_WSTAT_ON = 0x100, 0x200
 
 _fp = C.c_void_p
 
@@ -40,6 +42,7 @@ class ConvDesc(C.Structure):
         ("w_packed", _fp), ("bias", _fp), ("bias_stride_n", C.c_int32), ("res_mode", C.c_int32),
         ("res", _fp), ("out", _fp), ("out_layout", C.c_int32), ("stats_rows", C.c_int32),
         ("stats", _fp), ("workspace", _fp), ("workspace_bytes", C.c_size_t),
+        ("kernel_hint", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

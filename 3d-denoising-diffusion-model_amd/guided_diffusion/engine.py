@@ -18,6 +18,7 @@ depend on x, so all emb_layers are fused into one Linear whose output row
 for every step of the schedule.
 """
 
+import collections
 import ctypes as C
 import math
 import os
@@ -72,7 +73,7 @@ class UNetEngine:
         self.mc = model_channels
         self.film = film  # use_scale_shift_norm
         self.p = params    # name -> device fp32 tensor
-        self.plans = {}
+        self.plans = collections.OrderedDict()   # (N, D, H, W) -> _Plan, least recently used first
         st = H.stream()
         self.conv = {}
         self.winograd = os.environ.get("DDPM3D_WINOGRAD", "1") != "0"
@@ -134,12 +135,20 @@ class UNetEngine:
         return rows
 
     # ------------------------------------------------------------ plan building
+    MAX_PLANS = 4   # a plan owns every activation buffer of its shape; keep the last few shapes only
+
     def plan(self, N, D, Hh, W):
         key = (N, D, Hh, W)
         pl = self.plans.get(key)
         if pl is None:
+            while len(self.plans) >= self.MAX_PLANS:
+                # drop the least recently used shape (its launches are stream-ordered before anything
+                # the caching allocator hands the memory to next)
+                self.plans.popitem(last=False)
             pl = _Plan(self, N, D, Hh, W)
             self.plans[key] = pl
+        else:
+            self.plans.move_to_end(key)
         return pl
 
     def forward(self, x, low_res, film_rows, film_stride, out=None):
@@ -165,18 +174,34 @@ class _Plan:
         topo = eng.topo
         lib = eng.lib
 
+        # Activation buffers come from a pool keyed by size and go back to it when their last
+        # reader has been ENQUEUED (every step runs in order on one stream, so a later step may
+        # overwrite them): a plan holds the skip stack plus a handful of working tensors instead of
+        # one private buffer per layer (published net @ 64^3: 1.3 GB instead of 3 GB).
+        self.pool = {}
+        self.act_bytes = 0
+
         def new_act(Cn, d, h, w):
             # the statistics buffer is attached by the conv step that produces the tensor
             # (its row count depends on how that conv is tiled / split)
-            buf = torch.empty(N * d * h * w * Cn, dtype=torch.float32, device=dev)
-            act = Act(buf, Cn, d, h, w, None, 0)
-            self.keep.append(act)  # descriptors hold raw pointers: the plan owns every buffer
-            return act
+            numel = N * d * h * w * Cn
+            free = self.pool.get(numel)
+            if free:
+                buf = free.pop()
+            else:
+                buf = torch.empty(numel, dtype=torch.float32, device=dev)
+                self.act_bytes += 4 * numel
+                self.keep.append(buf)  # descriptors hold raw pointers: the plan owns every buffer
+            return Act(buf, Cn, d, h, w, None, 0)
+
+        def release(act):
+            self.pool.setdefault(act.buf.numel(), []).append(act.buf)
 
         self.ws_descs = []      # conv descriptors that need the shared split-K workspace
         self.ws_bytes = 0
 
         self.new_act = new_act
+        self.release = release
         first = topo.input[0][0]
         cin_conv = eng.conv[first.prefix]
         self.first_desc = None
@@ -184,16 +209,22 @@ class _Plan:
         self.first_desc = self.conv_step(cin_conv, srcs=None, out=h, planar=True)
         hs = [h]
         for blk in topo.input[1:]:
-            for e in blk:
-                h = self.layer(e, [h])
+            for i, e in enumerate(blk):
+                prev, h = h, self.layer(e, [h])
+                if i > 0:
+                    release(prev)          # a block's intermediate; its input stays on the skip stack
             hs.append(h)
         for e in topo.middle:
-            h = self.layer(e, [h])
+            prev, h = h, self.layer(e, [h])
+            if prev is not hs[-1]:
+                release(prev)
         for blk in topo.output:
             skip = hs.pop()
             srcs = [h, skip]
             for e in blk:
                 h = self.layer(e, srcs)
+                for a in srcs:
+                    release(a)
                 srcs = [h]
         # out: GN -> SiLU -> conv, stored NCDHW
         A, B = self.finalize([h], "out.0", None)
@@ -203,6 +234,7 @@ class _Plan:
         self.out_buf = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
         self.last_desc = self.conv_step(oc, srcs=[h], out=None, aff=(A, B), act=H.ACT_SILU,
                                         out_tensor=self.out_buf, out_layout=H.OUT_NCDHW)
+        release(h)
         # one split-K scratch buffer shared by every conv of the plan (they run in stream order)
         if self.ws_bytes:
             self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
@@ -247,6 +279,7 @@ class _Plan:
                 out.rows = lib.ddpm3d_conv_stats_rows(N, out.D, out.H, out.W, cin_total, pc.Cout, pc.k)
                 out.stats = torch.empty(N * out.rows * pc.Cout * 2, dtype=torch.float32,
                                         device=self.eng.device)
+                self.keep.append(out.stats)    # the descriptor holds a raw pointer
                 d.stats, d.stats_rows = H.ptr(out.stats), out.rows
         else:
             s = srcs[0]
@@ -278,6 +311,10 @@ class _Plan:
         d.w_packed, d.bias = H.ptr(pc_use.w), H.ptr(pc.b)
         d.bias_stride_n = 0  # per-sample bias rows are patched in run()
         d.res_mode = res_mode
+        if res is not None and res.C != pc.Cout:
+            # the epilogue reads the residual at stride Cout (ddpm3d.h): a narrower tensor would be
+            # read out of bounds
+            raise RuntimeError("residual has %d channels, the conv writes %d" % (res.C, pc.Cout))
         d.res = H.ptr(res.buf) if res is not None else 0
         need = lib.ddpm3d_conv_workspace_bytes(N, d.D, d.H, d.W, d.Cin, pc.Cout, pc.k)
         if need:
@@ -322,7 +359,9 @@ class _Plan:
                                [H.ptr(full.buf), N, x.D, x.H, x.W, pc.Cout, H.ptr(y.buf), 0]))
             y.rows = lib.ddpm3d_gn_stats_rows(y.voxels)
             y.stats = torch.empty(N * y.rows * pc.Cout * 2, dtype=torch.float32, device=eng.device)
+            self.keep.append(y.stats)
             self.steps.append((lib.ddpm3d_gn_stats, [H.ptr(y.buf), N, y.voxels, pc.Cout, H.ptr(y.stats), 0]))
+            self.release(full)
             return y
         raise ValueError(e.kind)
 
@@ -351,8 +390,10 @@ class _Plan:
         aprec = H.PREC_F32 if eng.precision == "f32" else H.PREC_F16X3
         self.steps.append((eng.lib.ddpm3d_attention_p,
                            [H.ptr(qkv.buf), N, x.voxels, heads, ch, aprec, H.ptr(a.buf), 0]))
+        self.release(qkv)
         y = self.new_act(Cn, x.D, x.H, x.W)
         self.conv_step(eng.conv[p + ".proj_out"], [a], y, res=x, res_mode=H.RES_SAME)
+        self.release(a)
         return y
 
     def resblock(self, e, srcs):
@@ -387,7 +428,14 @@ class _Plan:
             self.conv_step(skip, srcs, y, want_stats=False)   # y = skip(x), then accumulated into
             self.conv_step(c2, [h1], y, aff=(A2, B2), act=H.ACT_SILU, res=y, res_mode=H.RES_SAME)
         else:
+            if len(srcs) > 1:
+                # Identity skip over the decoder's virtual concat [h, skip] (2*inch == outch, e.g. a
+                # decreasing channel_mult on a directly built model): the residual would be the
+                # concatenation itself, which no epilogue mode reads.
+                raise NotImplementedError("ResBlock with an Identity skip over a concatenated input "
+                                          "(%d + %d -> %d channels)" % (srcs[0].C, srcs[1].C, c2.Cout))
             self.conv_step(c2, [h1], y, aff=(A2, B2), act=H.ACT_SILU, res=x0, res_mode=rm)
+        self.release(h1)
         return y
 
     # ---- execution -----------------------------------------------------------

@@ -223,6 +223,10 @@ class GaussianDiffusion:
             indices = tqdm(indices)
         model_kwargs = model_kwargs or {}
         fast = hasattr(model, "engine") and set(model_kwargs) == {"low_res"}
+        # grad mode and the current device are changed around the COMPUTE of a step only and are
+        # back to the caller's before every yield (the reference wraps p_sample alone in no_grad and
+        # yields outside it, gaussian_diffusion.py:524-535): an abandoned *_progressive generator
+        # leaves nothing changed.
         with th.no_grad(), th.cuda.device(device):
             t_all = th.arange(T, device=device, dtype=th.int64)[:, None].repeat(1, N).contiguous()
             if fast:
@@ -231,7 +235,8 @@ class GaussianDiffusion:
                 low_res = model_kwargs["low_res"].to(device).contiguous()
                 t_model = self._model_timesteps(th.arange(T, device=device, dtype=th.int64))
                 film = eng.film_rows(t_model.to(th.float32).contiguous())
-            for k, i in enumerate(indices):
+        for k, i in enumerate(indices):
+            with th.no_grad(), th.cuda.device(device):
                 t = t_all[i]
                 if fast:
                     out = eng.forward(img, low_res, film[i], 0)
@@ -244,8 +249,8 @@ class GaussianDiffusion:
                 else:
                     z = step_noise[k]
                 res = self._update(kind, out, img, t, z, clip_denoised, eta)
-                yield res
-                img = res["sample"]
+            yield res
+            img = res["sample"]
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
                                   cond_fn=None, model_kwargs=None, device=None, progress=False,

@@ -44,6 +44,26 @@ PUBLISHED = dict(large_size=96, small_size=96, num_channels=128, num_res_blocks=
 TINY = dict(PUBLISHED, num_channels=32, num_res_blocks=1)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: f16/bf16 MFMA, dense
+# Roofline peak per kernel family = MFMA peak of the instruction it issues / MFMAs it issues per
+# ALGORITHMIC product (achieved is always priced in the direct form's FLOPs):
+#   p0 exact fp32 MFMA 1;  p1 f16x3 direct 3;  p2 f16 direct 1;
+#   p3 f16x3 on the Winograd-D form 3 * 2/3 = 2;  p4 f16 on the Winograd-D form 2/3.
+PEAK_OF_TAG = {
+    "p0": (PEAK_F32_MFMA_TFLOPS, "fp32 MFMA dense (157.3), 1 MFMA per product"),
+    "p1": (PEAK_F16_MFMA_TFLOPS / 3.0, "f16 MFMA dense (2500) / 3 MFMAs per algorithmic fp32 product"),
+    "p2": (PEAK_F16_MFMA_TFLOPS, "f16 MFMA dense (2500), 1 MFMA per product"),
+    "p3": (PEAK_F16_MFMA_TFLOPS / 2.0, "f16 MFMA dense (2500) / 2 MFMAs per algorithmic fp32 product "
+                                       "(3 split products x 2/3 Winograd F(2,3) along depth)"),
+    "p4": (PEAK_F16_MFMA_TFLOPS * 1.5, "f16 MFMA dense (2500) x 3/2 (Winograd F(2,3) along depth issues "
+                                       "2/3 MFMA per algorithmic product)"),
+}
+
+
+def tag_peak(tag, fallback):
+    for k, v in PEAK_OF_TAG.items():
+        if ("_%s_" % k) in tag:
+            return v
+    return fallback
 # precision -> (dtype field, description of the conv arithmetic, basis of the roofline peak)
 ARITH = {
     "f32": ("f32", "exact fp32 MFMA", "fp32 MFMA dense"),
@@ -117,7 +137,10 @@ def main():
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
     ap.add_argument("--arch", choices=["published", "tiny"], default="published")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps for cpu_baseline (0 = skip)")
+    ap.add_argument("--f32-steps", type=int, default=25,
+                    help="DDPM steps of the same workload timed in the exact-fp32 arithmetic for the "
+                         "exact_f32 sub-record (0 = skip; only with the default f16x3 precision)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for cpu_baseline")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -168,6 +191,11 @@ def main():
         arch.update(large_size=args.large_size, small_size=args.large_size)
     if args.attention_resolutions is not None:
         arch.update(attention_resolutions=args.attention_resolutions)
+    # architecture overrides are named in config.workload (config 5 adds five attention blocks)
+    overrides = ""
+    if args.large_size is not None or args.attention_resolutions is not None:
+        overrides = "; OVERRIDES large_size=%s attention_resolutions=%s" % (
+            arch["large_size"], arch["attention_resolutions"])
     respacing = ("ddim%d" % args.ddpm_steps) if args.sampler == "ddim" else str(args.ddpm_steps)
     model, diff, sd = build_model(arch, respacing, device)
     model.conv_precision = args.precision
@@ -182,6 +210,9 @@ def main():
     eng = model.engine()
     plan = eng.plan(B, S, S, S)
     flops_fwd = sum(f for _, f in plan.conv_meta.values())
+    if overrides:
+        n_attn = sum(1 for l in model.topology.all_layers() if l.kind == "attn")
+        overrides += " (%d attention blocks)" % n_attn
     T = diff.num_timesteps
 
     def one_volume(step_index, measure):
@@ -262,11 +293,15 @@ def main():
             if tj.get("signature") == sig and k:
                 traffic, traffic_src = round(k["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(f)
                 break
+        kpeak, kbasis = tag_peak(tag, (peak, ARITH[args.precision][2]))
         roof = {
-            "bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": round(peak, 1),
-            "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "bound": "mfma", "kernel": tag, "achieved": round(ach, 2), "peak": round(kpeak, 1),
+            "unit": "TFLOP/s", "frac": round(ach / kpeak, 4), "traffic": traffic,
             "traffic_unit": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-            "peak_basis": ARITH[args.precision][2],
+            # PMC counters cannot be collected inside this process: the figure is the committed
+            # rocprofv3 pass over this same workload, not a measurement of this run
+            "traffic_static": traffic is not None,
+            "peak_basis": kbasis,
             "launches_timed": cnt, "avg_launch_ms": round(ms / cnt, 4),
             "all_conv_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                  "ms_per_forward": round(tot_ms / max(1, args.steps), 3),
@@ -274,6 +309,39 @@ def main():
             "per_kernel": {t: {"launches": a[0], "tflops": round(a[1] / (a[2] * 1e-3) / 1e12, 2),
                                "ms": round(a[2] / max(1, args.steps), 3)} for t, a in sorted(by_tag.items())},
         }
+
+    # the same workload in the EXACT fp32 arithmetic (v_mfma_f32_32x32x2_f32), a bounded number of
+    # steps: the driver-timed record then carries an exact-arithmetic number beside the default one
+    exact = None
+    if args.precision == "f16x3" and args.f32_steps > 0 and rank == 0 and world == 1:
+        model.conv_precision = "f32"
+        eng32 = model.engine()
+        k_steps = min(args.f32_steps, T)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(77)
+        noise = torch.randn(*shape, device=device, generator=gen)
+        loop = diff.ddim_sample_loop_progressive if args.sampler == "ddim" else diff.p_sample_loop_progressive
+
+        def run_steps(n):
+            for k, _ in enumerate(loop(model, shape, noise, model_kwargs={"low_res": lr})):
+                if k + 1 >= n:
+                    break
+        run_steps(2)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        run_steps(k_steps)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        fl32 = sum(f for _, f in eng32.plan(B, S, S, S).conv_meta.values())
+        tf = fl32 * k_steps / dt / 1e12
+        exact = {"precision": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)", "steps_timed": k_steps,
+                 "ms_per_ddpm_step": round(1000.0 * dt / k_steps, 3),
+                 "value": B / (dt / k_steps * T), "unit": "volumes/s (extrapolated to %d steps)" % T,
+                 "tflops": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                 "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                 "note": "whole step (all kernels), wall clock; conv FLOPs only"}
+        model.conv_precision = args.precision
+        log("[bench] exact fp32 arithmetic: %d steps in %.2fs (%.1f TFLOP/s)" % (k_steps, dt, tf))
 
     if rank == 0:
         vols = args.steps * B * world
@@ -297,13 +365,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx1x%d^3 volume(s) per GPU, %d %s steps, %s architecture "
                                    "(SuperResModel_noatt, %d base ch, mult (1,1,2,3,4), %d res blocks, "
-                                   "learn_sigma), seeded random weights, device RNG"
+                                   "learn_sigma%s), seeded random weights, device RNG"
                                    % (B, S, T, args.sampler.upper(), args.arch, arch["num_channels"],
-                                      arch["num_res_blocks"]),
+                                      arch["num_res_blocks"], overrides),
                        "parallelism": "independent volumes per rank (dp%d), all_gather of finished samples" % world,
                        "tflop_per_volume": round(flops_fwd * T / B / 1e12, 1),
                        "conv_arithmetic": ARITH[args.precision][1]},
             "roofline": roof,
+            "exact_f32": exact,
         }
         if world == 1 and args.cpu_steps > 0:
             threads = os.cpu_count() or 1

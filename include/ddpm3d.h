@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define DDPM3D_ABI_VERSION 7
+#define DDPM3D_ABI_VERSION 8
 
 enum {
     DDPM3D_OK = 0,
@@ -114,7 +114,18 @@ typedef struct ddpm3d_conv_desc {
      * may be shared by all convs of a stream, NULL when that query returns 0 */
     void* workspace;
     size_t workspace_bytes;
+    /* 0 = the library picks the workgroup order from the shape.  DDPM3D_HINT_* bits select among
+     * launch orders of IDENTICAL arithmetic (bit-identical outputs); they exist for tests and A/B
+     * measurements and never change a result. */
+    int32_t kernel_hint;
+    int32_t reserved0;
 } ddpm3d_conv_desc;
+
+/* ddpm3d_conv_desc.kernel_hint */
+enum {
+    DDPM3D_HINT_WSTAT_OFF = 0x100,/* workgroup -> XCD order: tiles fastest (activation-stationary)   */
+    DDPM3D_HINT_WSTAT_ON = 0x200  /*   cout blocks / K splits fastest (weight-stationary)            */
+};
 
 int ddpm3d_abi_version(void);
 const char* ddpm3d_last_error(void);

@@ -44,3 +44,16 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def rel_err_per_channel(a, b, axis=1):
+    """max over channels c of  max|a_c - b_c| / max|b_c|  -- each channel (e.g. the eps and the
+    variance channel of the model output) is held to the bar on its own scale, so a small channel
+    cannot hide behind a large one."""
+    a = np.moveaxis(np.asarray(a, dtype=np.float64), axis, 0)
+    b = np.moveaxis(np.asarray(b, dtype=np.float64), axis, 0)
+    a = a.reshape(a.shape[0], -1)
+    b = b.reshape(b.shape[0], -1)
+    num = np.abs(a - b).max(axis=1)
+    den = np.maximum(np.abs(b).max(axis=1), 1e-30)
+    return float((num / den).max())

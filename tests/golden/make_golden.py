@@ -217,6 +217,37 @@ def gen_sampler():
     save("sampler.npz", **out)
 
 
+def gen_sampler_published250():
+    """Long-horizon pin: the PUBLISHED architecture through all 250 steps of timestep_respacing="250"
+    on a 1x1x8x32x32 volume (the north_star bar is 1e-3 at 250 dependent steps on this network).
+    Keeps the final sample, a few intermediate samples (error growth along the chain) and the
+    per-step means."""
+    shape = (1, 1, 8, 32, 32)
+    model, diff = ref_su.sr_create_model_and_diffusion(**flags(**dict(PUBLISHED, timestep_respacing="250")))
+    load_synth(model)
+    T = diff.num_timesteps
+    assert T == 250
+    draws = synth.synth_noise(shape, T + 1, seed=10)
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234))
+    keep_at = (50, 100, 150, 200, 240)     # number of completed steps
+    out, trace = {}, []
+    with _InjectNoise(draws[1:]), torch.no_grad():
+        gen = diff.p_sample_loop_progressive(model, shape, torch.from_numpy(draws[0]),
+                                             model_kwargs={"low_res": lr})
+        for i, o in enumerate(gen):
+            s = o["sample"]
+            trace.append((float(s.mean()), float(o["pred_xstart"].mean()), float(s.std())))
+            if i + 1 in keep_at:
+                out["after%d" % (i + 1)] = s.numpy().copy()
+            last = o
+            if (i + 1) % 25 == 0:
+                print("published250: step", i + 1, trace[-1], flush=True)
+    out["sample"] = last["sample"].numpy()
+    out["pred_xstart"] = last["pred_xstart"].numpy()
+    out["trace"] = np.array(trace, dtype=np.float64)
+    save("sampler_published250.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["schedules", "temb", "keys", "resblocks", "unet", "sampler"]
     if "schedules" in which:
@@ -231,3 +262,5 @@ if __name__ == "__main__":
         gen_unet_forward()
     if "sampler" in which:
         gen_sampler()
+    if "sampler250" in which:       # ~10 CPU-minutes; not part of the default list
+        gen_sampler_published250()

@@ -27,7 +27,7 @@ def pack(w, precision=0):
 
 
 def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res=None, res_mode=H.RES_NONE,
-           out_layout=H.OUT_NDHWC, want_stats=True, planar=False, bias_stride_n=0, precision=0):
+           out_layout=H.OUT_NDHWC, want_stats=True, planar=False, bias_stride_n=0, precision=0, hint=0):
     """srcs: list of NDHWC device tensors (or two (N,1,D,H,W) volumes when planar).
     Returns (out, stats, rows)."""
     lib = H.load()
@@ -51,6 +51,7 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
         d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
     d.act = act
     d.precision = precision
+    d.kernel_hint = hint
     wp = pack(w, precision)
     d.w_packed, d.bias, d.bias_stride_n = H.ptr(wp), H.ptr(b), bias_stride_n
     d.res_mode, d.res = res_mode, H.ptr(res)

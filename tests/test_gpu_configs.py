@@ -1,0 +1,159 @@
+"""
+BASELINE.json's configurations at (or as near as a test can get to) their stated workloads,
+on the GPU, through the HIP engine:
+
+  C2  published architecture, 250 dependent DDPM steps -- pinned to the REFERENCE's own
+      250-step run (tests/golden/sampler_published250.npz, 1x1x8x32x32) at the north_star
+      bar (1e-3), in the exact-fp32 and in the default f16x3 arithmetic;
+  C3  one GPU's share of the 8-GPU run: 8 volumes of 64^3 in one launch train, each equal to
+      its batch-1 result;
+  C4  50-step DDIM (respace.py "ddim50"), published architecture, 1x64^3, convert_to_fp16();
+  C5  1x128^3 with attention at ds 8 (T = 32 768 tokens): full-size properties;
+  and the kernel that only full-size grids select (conv3d_wzs_kernel, 128->128 @ 64^3)
+  checked DIRECTLY against F.conv3d on the CPU.
+
+Full-size cases cannot be compared with the CPU oracle inside a test (a published-architecture
+forward at 64^3 takes the oracle 5-12 s, a 250-step volume an hour), so they are held to
+size-independent properties against the exact-fp32 mode, which is itself pinned to the
+reference at reduced sizes (test_gpu_model.py and the 250-step case here).
+"""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err, rel_err_per_channel
+from guided_diffusion import synth
+from test_gpu_model import PUBLISHED, build, inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_c2_published_250_steps_vs_reference_golden(golden, precision):
+    """The north_star bar as stated: 1e-3 relative after 250 DEPENDENT steps on the published
+    architecture.  Intermediate samples show how the difference grows along the chain."""
+    g = golden("sampler_published250.npz")
+    model, diff = build(PUBLISHED, "250", precision=precision)
+    shape = (1, 1, 8, 32, 32)
+    T = diff.num_timesteps
+    assert T == 250
+    draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, T + 1, seed=10)]
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234)).cuda()
+    trace, errs = [], {}
+    for k, o in enumerate(diff.p_sample_loop_progressive(model, shape, draws[0], model_kwargs={"low_res": lr},
+                                                         step_noise=draws[1:])):
+        s = o["sample"]
+        trace.append((float(s.mean()), float(o["pred_xstart"].mean()), float(s.std())))
+        key = "after%d" % (k + 1)
+        if key in g.files:
+            errs[key] = rel_err(s.cpu().numpy(), g[key])
+        last = o
+    errs["sample"] = rel_err(last["sample"].cpu().numpy(), g["sample"])
+    errs["pred_xstart"] = rel_err(last["pred_xstart"].cpu().numpy(), g["pred_xstart"])
+    print("250-step published (%s): rel err along the chain %s" % (precision, errs))
+    assert max(errs.values()) < 1e-3, errs
+    assert np.allclose(np.array(trace), g["trace"], rtol=1e-3, atol=1e-4)
+
+
+def test_c3_batch8_per_gpu_share_matches_batch1():
+    """BASELINE config 3 gives each of 8 GPUs 8 volumes of 64^3.  One forward of that batch:
+    every volume must equal its own batch-1 result (other tile counts / split-K factors change
+    summation orders only)."""
+    B = 8
+    shape1 = (1, 1, 64, 64, 64)
+    xs = [torch.from_numpy(synth.synth_noise(shape1, 1, seed=20 + b)[0]) for b in range(B)]
+    lrs = [torch.from_numpy(synth.synth_low_res(shape1, seed=300 + b)) for b in range(B)]
+    ts = [617, 41, 999, 0, 5, 250, 761, 333]
+    model, _ = build(PUBLISHED)
+    with torch.no_grad():
+        yb = model(torch.cat(xs).cuda(), torch.tensor(ts).cuda(), low_res=torch.cat(lrs).cuda()).cpu().numpy()
+        assert yb.shape == (B, 2, 64, 64, 64) and np.isfinite(yb).all()
+        for b in range(B):
+            y1 = model(xs[b].cuda(), torch.tensor(ts[b:b + 1]).cuda(), low_res=lrs[b].cuda()).cpu().numpy()
+            assert rel_err_per_channel(yb[b:b + 1], y1) < 2e-5, b
+
+
+def test_c4_ddim50_published_fp16_mode_psnr():
+    """BASELINE config 4's run: published architecture, 1x64^3, "ddim50", eta 0, with
+    model.convert_to_fp16() (scripts/test.py:33-34).  There is no reduced-precision CPU oracle
+    (the reference's fp16 path does not run on CPU), so the judge is PSNR against the
+    fp32-grade default mode on the same noise.  Bar: operands rounded to f16 carry 2^-11 relative
+    error each; over a K = 3456 reduction the output error is ~2^-11 / sqrt(K) * |w||x| ~ 1e-4
+    relative per layer, and 50 clipped DDIM steps measured 55-70 dB on the tiny network -- 45 dB
+    (error 5.6e-3 of the [-1, 1] range) leaves room for the deeper network without admitting a
+    wrong kernel (a dropped tap or channel costs > 20 dB)."""
+    shape = (1, 1, 64, 64, 64)
+    draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, 51, seed=10)]
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234)).cuda()
+    model, diff = build(PUBLISHED, "ddim50")
+    assert diff.num_timesteps == 50 and list(diff.timestep_map[:3]) == [0, 20, 40]
+    ref = diff.ddim_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
+    model.convert_to_fp16()
+    assert model.dtype == torch.float16
+    out = diff.ddim_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
+    assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6   # last step is clipped x0
+    mse = float(((out - ref) ** 2).mean())
+    psnr = 10 * np.log10(4.0 / max(mse, 1e-30))
+    print("config 4 (ddim50, f16 operands) PSNR vs f16x3: %.1f dB" % psnr)
+    assert psnr > 45.0, psnr
+
+
+def test_c5_full_size_attention_forward_properties():
+    """BASELINE config 5 at FULL size: large_size=128, attention_resolutions="16" (attention at
+    ds 8: T = 128*16*16 = 32 768 tokens, 5 blocks), 1x128^3.  Default arithmetic vs the exact-fp32
+    mode, bitwise repeatability, finiteness."""
+    arch = dict(PUBLISHED, large_size=128, small_size=128, attention_resolutions="16")
+    shape = (1, 1, 128, 128, 128)
+    x, lr = inputs(shape)
+    t = torch.tensor([444])
+    model, _ = build(arch)
+    assert sum(1 for l in model.topology.all_layers() if l.kind == "attn") == 5
+    with torch.no_grad():
+        y = model(x.cuda(), t.cuda(), low_res=lr.cuda())
+        y_again = model(x.cuda(), t.cuda(), low_res=lr.cuda())
+    assert tuple(y.shape) == (1, 2, 128, 128, 128) and torch.isfinite(y).all()
+    assert torch.equal(y, y_again)
+    y_def = y.cpu().numpy()
+    del model, y, y_again
+    torch.cuda.empty_cache()
+    exact, _ = build(arch, precision="f32")
+    with torch.no_grad():
+        y_exact = exact(x.cuda(), t.cuda(), low_res=lr.cuda()).cpu().numpy()
+    del exact
+    torch.cuda.empty_cache()
+    assert rel_err_per_channel(y_def, y_exact) < 1e-4
+
+
+@pytest.mark.parametrize("ci,upsampled", [(128, False), (256, False), (128, True)])
+def test_full_size_winograd_kernel_vs_cpu_conv(ci, upsampled):
+    """The kernel the 64^3 level auto-selects (>= 2048 workgroups: the wave-specialised, persistent
+    Winograd-D form) compared DIRECTLY with F.conv3d on the CPU: ci -> 128 @ 64x64x64, GroupNorm-style
+    affine + SiLU prologue, residual and statistics, precision 3 -- the layer shapes that carry
+    60 % of the forward.  256 = the decoder's virtual concat of two 128-channel tensors; upsampled =
+    the up-ResBlock's nearest-neighbour input mode."""
+    import hipcall as hc
+    import guided_diffusion._hip as H
+    from test_gpu_ops import TOL, check_stats, rnd
+    D = Hh = W = 64
+    hs, ws = (Hh // 2, W // 2) if upsampled else (Hh, W)
+    x = rnd(1, ci, D, hs, ws, seed=1)
+    w = rnd(128, ci, 3, 3, 3, seed=2, scale=0.03)
+    b = rnd(128, seed=3)
+    a = 1.0 + 0.1 * rnd(1, ci, seed=4)
+    bb = 0.1 * rnd(1, ci, seed=5)
+    res = rnd(1, 128, D, Hh, W, seed=6)
+    xin = F.silu(x * a[:, :, None, None, None] + bb[:, :, None, None, None])
+    if upsampled:
+        xin = F.interpolate(xin, (D, Hh, W), mode="nearest")
+    torch.set_num_threads(16)
+    ref = F.conv3d(xin, w, b, padding=1) + res
+    xd = hc.to_ndhwc(x).cuda()
+    srcs = [xd] if ci == 128 else [xd[..., :128].contiguous(), xd[..., 128:].contiguous()]
+    out, stats, _ = hc.conv3d(srcs, w.cuda(), b.cuda(), (D, Hh, W), aff=(a.cuda(), bb.cuda()), act=H.ACT_SILU,
+                              in_mode=H.IN_UP if upsampled else H.IN_SAME,
+                              res=hc.to_ndhwc(res).cuda(), res_mode=H.RES_SAME, precision=3)
+    got = hc.to_ncdhw(out.cpu())
+    assert rel_err_per_channel(got.numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)

@@ -70,7 +70,7 @@ def test_conv_desc_struct_layout_matches_header():
     assert f["src0"] == 32 and f["C0"] == 48 and f["aff_a"] == 56 and f["act"] == 72
     assert f["w_packed"] == 80 and f["bias_stride_n"] == 96 and f["res"] == 104 and f["out"] == 112
     assert f["out_layout"] == 120 and f["stats"] == 128 and f["workspace"] == 136
-    assert f["workspace_bytes"] == 144 and ctypes.sizeof(_hip.ConvDesc) == 152
+    assert f["workspace_bytes"] == 144 and f["kernel_hint"] == 152 and ctypes.sizeof(_hip.ConvDesc) == 160
 
 
 def test_sr_defaults_and_flag_parsing():

@@ -161,3 +161,27 @@ def test_sampler_loops(golden, tag, over, shape, resp, kind, eta, kw):
     g = golden("sampler.npz")
     assert rel_err(out.numpy(), g[tag + "/sample"]) < 1e-5, tag
     assert np.allclose(np.array(trace), g[tag + "/trace"], rtol=1e-4, atol=1e-5)
+
+
+def test_published_250_step_chain_head(golden):
+    """The long-horizon golden (published architecture, timestep_respacing "250", 1x1x8x32x32,
+    tests/golden/sampler_published250.npz) is what the GPU path is held to at 250 steps; here the
+    oracle walks the first steps of the same chain (the whole chain is ~2.5 CPU-minutes) and must
+    reproduce the reference's per-step sample mean / pred_xstart mean / sample std."""
+    g = golden("sampler_published250.npz")
+    cfg = unet_ref.sr_config(**PUBLISHED)
+    sd = _sd(cfg)
+    shape = (1, 1, 8, 32, 32)
+    tmap, tb = schedule_ref.spaced_schedule(1000, "linear", "250")
+    steps = 5
+    draws = [torch.from_numpy(a) for a in synth.synth_noise(shape, 251, seed=10)]
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234))
+    img, rows = draws[0], []
+    with torch.no_grad():
+        for k in range(steps):
+            i = 249 - k
+            out = unet_ref.unet_forward(sd, cfg, img, torch.full((1,), tmap[i], dtype=torch.long), lr)
+            mean, log_var, x0 = sampler_ref.mean_variance(tb, out, img, i)
+            img = mean + torch.exp(0.5 * log_var) * draws[k + 1]
+            rows.append((float(img.mean()), float(x0.mean()), float(img.std())))
+    assert np.allclose(np.array(rows), g["trace"][:steps], rtol=1e-5, atol=1e-6)
