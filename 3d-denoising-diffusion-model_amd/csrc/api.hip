@@ -123,6 +123,14 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     k.stats_rows = c.stats_rows;
     k.reduce_vox = c.reduce_vox;
     k.hint = d->kernel_hint;
+    if (d->precision != DDPM3D_PREC_F32) {
+        if (!d->in_bound || d->in_bound_count <= 0 || d->in_bound_count > 64 || d->in_bound_stride <= 0)
+            return fail(DDPM3D_EINVAL, "conv3d: the split-f16 precisions need in_bound (1..64 entries per sample): "
+                                       "the activation scale is derived from it, nothing is clamped");
+        k.in_bound = d->in_bound;
+        k.in_bound_count = d->in_bound_count;
+        k.in_bound_stride = d->in_bound_stride;
+    }
     k.ksplit = c.S;
     k.chunks_per_split = (k.CinPad / DDPM3D_CONV_CK + c.S - 1) / c.S;
     k.partial = (float*)d->workspace;
@@ -162,19 +170,25 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
 int ddpm3d_gn_finalize(const float* stats0, int C0, int rows0, const float* stats1, int C1, int rows1,
                        int N, int groups, double count, float eps, const float* gamma, const float* beta,
                        const float* film, int film_stride, int film_off, float* aff_a, float* aff_b,
-                       void* stream) {
+                       float* bound, void* stream) {
     const int C = C0 + C1;
-    if (!stats0 || !gamma || !beta || !aff_a || !aff_b || N <= 0 || groups <= 0 || C0 <= 0 || C1 < 0 ||
-        rows0 <= 0 || count <= 0)
+    if (!stats0 || N <= 0 || groups <= 0 || C0 <= 0 || C1 < 0 || rows0 <= 0 || count <= 0)
         return fail(DDPM3D_EINVAL, "gn_finalize: bad arguments");
+    if (gamma ? (!beta || !aff_a || !aff_b) : !bound)
+        return fail(DDPM3D_EINVAL, "gn_finalize: gamma needs beta, aff_a, aff_b; without gamma only `bound` is written");
     if (C % groups) return fail(DDPM3D_EINVAL, "gn_finalize: C=%d not divisible by %d groups", C, groups);
     const int cg = C / groups;
     if (C1 > 0 && (!stats1 || rows1 <= 0 || C0 % cg))
         return fail(DDPM3D_EINVAL, "gn_finalize: a group straddles the concat boundary (C0=%d, group=%d)", C0, cg);
     return launched(ddpm3d_launch_gn_finalize(stats0, C0, rows0, stats1, C1, rows1, N, groups, count, eps,
-                                              gamma, beta, film, film_stride, film_off, aff_a, aff_b,
+                                              gamma, beta, film, film_stride, film_off, aff_a, aff_b, bound,
                                               (hipStream_t)stream),
                     "gn_finalize");
+}
+
+int ddpm3d_absmax(const float* x0, const float* x1, int N, size_t per_sample, float* bound, void* stream) {
+    if (!x0 || !bound || N <= 0 || per_sample == 0) return fail(DDPM3D_EINVAL, "absmax: bad arguments");
+    return launched(ddpm3d_launch_absmax(x0, x1, N, per_sample, bound, (hipStream_t)stream), "absmax");
 }
 
 int ddpm3d_gn_stats_rows(int voxels) { return voxels > 0 ? ddpm3d_gn_stats_rows_impl(voxels) : 0; }
@@ -215,20 +229,23 @@ int ddpm3d_subsample_hw2(const float* in, int N, int D, int H, int W, int C, flo
     return launched(ddpm3d_launch_subsample_hw2(in, N, D, H, W, C, out, (hipStream_t)stream), "subsample_hw2");
 }
 
-int ddpm3d_attention_p(const float* qkv, int N, int T, int heads, int head_channels, int precision, float* out,
-                       void* stream) {
+int ddpm3d_attention_p(const float* qkv, int N, int T, int heads, int head_channels, int precision,
+                       const float* qkv_bound, int bound_count, int bound_stride, float* out, void* stream) {
     if (!qkv || !out || N <= 0 || T <= 0 || heads <= 0) return fail(DDPM3D_EINVAL, "attention: bad arguments");
     if (head_channels != 32 && head_channels != 64 && head_channels != 128)
         return fail(DDPM3D_ENOSUP, "attention: %d channels per head (32, 64 or 128 are built)", head_channels);
     if (precision != DDPM3D_PREC_F32 && precision != DDPM3D_PREC_F16X3)
         return fail(DDPM3D_ENOSUP, "attention: precision %d (F32 and F16X3 are built)", precision);
     if (!aligned16(qkv) || !aligned16(out)) return fail(DDPM3D_EINVAL, "attention: buffers must be 16-byte aligned");
-    return launched(ddpm3d_launch_attention(qkv, N, T, heads, head_channels, precision, out, (hipStream_t)stream),
+    if (precision != DDPM3D_PREC_F32 && (!qkv_bound || bound_count <= 0 || bound_count > 64 || bound_stride <= 0))
+        return fail(DDPM3D_EINVAL, "attention: the split-f16 arithmetic needs qkv_bound (1..64 entries per sample)");
+    return launched(ddpm3d_launch_attention(qkv, N, T, heads, head_channels, precision, qkv_bound, bound_count,
+                                            bound_stride, out, (hipStream_t)stream),
                     "attention");
 }
 
 int ddpm3d_attention(const float* qkv, int N, int T, int heads, int head_channels, float* out, void* stream) {
-    return ddpm3d_attention_p(qkv, N, T, heads, head_channels, DDPM3D_PREC_F32, out, stream);
+    return ddpm3d_attention_p(qkv, N, T, heads, head_channels, DDPM3D_PREC_F32, nullptr, 0, 0, out, stream);
 }
 
 static int step_args_ok(const float* mo, const float* x, const float* noise, const float* coef,

@@ -150,32 +150,49 @@ __global__ __launch_bounds__(256, (CH == 128 ? 2 : 3)) void attention_kernel(con
 // Rows are padded to an ODD number of 16-byte slots: a ds_read_b128 is served in 16-lane groups
 // whose rows are distinct mod 16, so odd strides are conflict-free (MI355X_MICROARCH.md, LDS).
 //
-// Power-of-two scales keep the lo parts normal f16: Q, K, V x2^3 (clamped to +-60000 like the
-// convs' activations), P in [0,1] x2^12; the scores are un-scaled (x2^-6, exact) before the fp32
-// softmax and the output's 2^15 is folded into the final 1/l.  exp is exp2(x*log2 e) (v_exp_f32).
+// Power-of-two scales keep the lo parts normal f16 and the hi parts finite: Q, K, V x S, with S the
+// power of two that puts the caller's bound of |qkv| just below 2^15 (qkv_scale below; nothing is
+// clamped), P in [0,1] x2^12; the scores are un-scaled (x S^-2, exact) before the fp32 softmax and
+// the output's S * 2^12 is folded into the final 1/l.  exp is exp2(x*log2 e) (v_exp_f32).
 typedef _Float16 ah8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ah4 __attribute__((ext_vector_type(4)));
 
 struct HiLo { _Float16 hi, lo; };
 __device__ __forceinline__ HiLo split_f16(float x, float scale) {
-    const float s = fminf(fmaxf(x * scale, -60000.0f), 60000.0f);
+    const float s = x * scale;
     HiLo r;
     r.hi = (_Float16)s;
     r.lo = (_Float16)(s - (float)r.hi);
     return r;
 }
 
+// S = 2^(14 - floor(log2 b)), b = the largest of sample n's bound entries (uniform over the workgroup)
+__device__ __forceinline__ float qkv_scale(const float* __restrict__ bound, int count, int stride, int n) {
+    const int lane = threadIdx.x & 63;
+    float b = 0.0f;
+    if (lane < count) b = bound[((size_t)n * count + lane) * stride];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b)));
+    const int e = (int)((__builtin_bit_cast(unsigned, b) >> 23) & 0xffu) - 127;
+    int k = 14 - e;
+    if (!(b > 0.0f) || e == 128) k = 0;
+    k = k < -40 ? -40 : (k > 40 ? 40 : k);
+    return __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+}
+
 // (waves per SIMD stated explicitly: with the bare bound the compiler keeps the MFMA accumulators
 // in AGPRs and spends 144 v_accvgpr_read/write per tile moving them around the softmax)
 template <int CH>
 __global__ __launch_bounds__(256, (CH == 128 ? 2 : 3)) void attention_x3_kernel(const float* __restrict__ qkv, int T, int heads,
+                                                           const float* __restrict__ bound, int bcount, int bstride,
                                                            float* __restrict__ out) {
     constexpr int KT = 32;                    // keys per tile
     constexpr int KS = CH / 16;               // k-steps of the first product
     constexpr int CT = CH / 32;               // 32-channel output tiles
     constexpr int KROW = CH * 2 + 16;         // bytes per K row (f16): CH/8 + 1 slots, odd
     constexpr int VROW = KT * 2 + 16;         // bytes per V^T row (32 keys, f16): 5 slots
-    constexpr float QKV_SCALE = 8.0f, P_SCALE = 4096.0f;
+    constexpr float P_SCALE = 4096.0f;
     static_assert(((KROW / 16) & 1) == 1 && ((VROW / 16) & 1) == 1, "odd slot strides");
     __shared__ __attribute__((aligned(16))) unsigned char Kh[KT * KROW], Kl[KT * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char Vh[CH * VROW], Vl[CH * VROW];
@@ -186,6 +203,7 @@ __global__ __launch_bounds__(256, (CH == 128 ? 2 : 3)) void attention_x3_kernel(
     const int n = nh / heads, head = nh % heads;
     const int C3 = heads * 3 * CH;
     const float* base = qkv + (size_t)n * T * C3 + (size_t)head * 3 * CH;
+    const float QKV_SCALE = qkv_scale(bound, bcount, bstride, n);
     const int q0 = blockIdx.x * 128 + wave * 32;
     const int tq = q0 + qi;
     const bool qvalid = tq < T;
@@ -289,7 +307,7 @@ __global__ __launch_bounds__(256, (CH == 128 ? 2 : 3)) void attention_x3_kernel(
 
         // Scores stay in their x 2^6 units (max and differences do not care); the un-scaling and
         // exp's log2(e) are one constant in the exp2 argument.  Only the ragged last tile masks.
-        constexpr float EXP2_C = 1.44269504088896341f / (QKV_SCALE * QKV_SCALE);
+        const float EXP2_C = 1.44269504088896341f / (QKV_SCALE * QKV_SCALE);
         if (k0 + KT > T) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -351,16 +369,16 @@ __global__ __launch_bounds__(256, (CH == 128 ? 2 : 3)) void attention_x3_kernel(
     }
 }
 
-hipError_t ddpm3d_launch_attention(const float* qkv, int N, int T, int heads, int ch, int precision, float* out,
-                                   hipStream_t st) {
+hipError_t ddpm3d_launch_attention(const float* qkv, int N, int T, int heads, int ch, int precision,
+                                   const float* bound, int bcount, int bstride, float* out, hipStream_t st) {
     dim3 grid((T + 127) / 128, N * heads);
     if (precision != DDPM3D_PREC_F32) {
         if (ch == 64)
-            hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, st, qkv, T, heads, out);
+            hipLaunchKernelGGL(attention_x3_kernel<64>, grid, dim3(256), 0, st, qkv, T, heads, bound, bcount, bstride, out);
         else if (ch == 32)
-            hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, st, qkv, T, heads, out);
+            hipLaunchKernelGGL(attention_x3_kernel<32>, grid, dim3(256), 0, st, qkv, T, heads, bound, bcount, bstride, out);
         else if (ch == 128)
-            hipLaunchKernelGGL(attention_x3_kernel<128>, grid, dim3(256), 0, st, qkv, T, heads, out);
+            hipLaunchKernelGGL(attention_x3_kernel<128>, grid, dim3(256), 0, st, qkv, T, heads, bound, bcount, bstride, out);
         else
             return hipErrorInvalidValue;
         return hipGetLastError();

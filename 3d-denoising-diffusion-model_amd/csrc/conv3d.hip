@@ -122,6 +122,8 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
     const int up_shift = p.in_mode == DDPM3D_IN_UP ? 1 : 0;
     const unsigned act_mask = p.act ? 0xFFFFFFFFu : 0u;
     f32x4 raw[PIPE ? NL : 1];
+    ActScale asc = {1.0f, 1.0f};
+    if constexpr (PREC != 0) asc = act_scale(p, n, 1.0f);
     HaloSrc hs = halo_src<CK>(p, n, chunk_begin < chunk_end ? chunk_begin : 0, q);
     // source voxel of each staging item (-1 = zero padding): launch-invariant, one VGPR each
     int vox[PIPE ? NL : 1];
@@ -165,8 +167,7 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
                     h4 hi, lo;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        // x8: keeps lo = x - hi a normal f16 down to |x| ~ 2^-6; clamp keeps hi finite
-                        const float s = fminf(fmaxf(v[c] * DDPM3D_X3_ACT_SCALE, -60000.0f), 60000.0f);
+                        const float s = v[c] * asc.s;   // |s| < 2^15 by the choice of the scale
                         hi[c] = (_Float16)s;
                         lo[c] = (_Float16)(s - (float)hi[c]);
                     }
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
     if (!wave_active) return;
 
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<PREC, WM, MT, TXL, TYL>(p, acc, n, z0, y0, x0, tile_in_n, wm, cout, half, wg.split);
+    conv_epilogue<PREC, WM, MT, TXL, TYL>(p, acc, n, z0, y0, x0, tile_in_n, wm, cout, half, wg.split, asc.inv);
 }
 
 // This file is compiled once per arithmetic mode (-DDDPM3D_PREC_ONLY=0|1|2, see the

@@ -20,14 +20,16 @@ struct LdsGeom {
 // Epilogue shared by the conv kernels: bias / residual / store / GroupNorm partial sums, or
 // the raw split-K slab.  C/D map of a 32x32 MFMA: col = lane&31 (cout),
 // row = (reg&3) + 8*(reg>>2) + 4*half.
+// inv_act = 1 / activation scale of this sample (split-f16 modes; 1 in the exact mode)
 template <int PREC, int WM, int MT, int TXL, int TYL>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc)[MT], int n, int z0, int y0,
-                                              int x0, int tile_in_n, int wm, int cout, int half, int ksplit_idx) {
+                                              int x0, int tile_in_n, int wm, int cout, int half, int ksplit_idx,
+                                              float inv_act) {
     constexpr int TX = 1 << TXL, TY = 1 << TYL;
     const bool cvalid = cout < p.Cout;
     const size_t DHW = (size_t)p.D * p.H * p.W;
     // PREC 1/2: undo the operand scaling (exact: a power of two per cout)
-    const float oscale = (PREC != 0 && cvalid) ? p.wscale[cout] : 1.0f;
+    const float oscale = (PREC != 0 && cvalid) ? p.wscale[cout] * inv_act : 1.0f;
 
     // Fast path -- every launch of the network except ragged edge tiles, the NCDHW output conv
     // and the up/down-sampling skip sums: the tile lies inside the volume, so element (t, reg)

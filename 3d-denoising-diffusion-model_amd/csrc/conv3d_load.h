@@ -149,6 +149,27 @@ __device__ __forceinline__ f32x4 halo_finish(const HaloSrc& h, f32x4 raw, bool i
     return r;
 }
 
+// Power-of-two activation scale of sample n (split-f16 modes; uniform over the workgroup): the
+// maximum b of the sample's in_bound entries, times `gain` (2 for the Winograd-D input transform,
+// which adds two planes), is brought into [2^14, 2^15): s = 2^(14 - floor(log2(gain * b))).
+struct ActScale { float s, inv; };
+__device__ __forceinline__ ActScale act_scale(const ConvK& p, int n, float gain) {
+    const int lane = threadIdx.x & 63;
+    float b = 0.0f;
+    if (lane < p.in_bound_count) b = p.in_bound[((size_t)n * p.in_bound_count + lane) * p.in_bound_stride];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o));   // a NaN entry is ignored
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b))) * gain;
+    const int e = (int)((__builtin_bit_cast(unsigned, b) >> 23) & 0xffu) - 127;   // floor(log2 b), b normal
+    int k = 14 - e;
+    if (!(b > 0.0f) || e == 128) k = 0;          // all-zero input, or a non-finite bound
+    k = k < -60 ? -60 : (k > 60 ? 60 : k);
+    ActScale r;
+    r.s = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+    r.inv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+    return r;
+}
+
 // Which (tile, cout block, K split) a workgroup owns.  Workgroups go to the 8 XCDs round-robin
 // in linear-id order (x fastest), and each XCD has its own L2:
 //   - default (activations outweigh weights): consecutive TILES on one XCD (xcd_remap), so the

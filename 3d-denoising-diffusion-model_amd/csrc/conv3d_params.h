@@ -8,11 +8,11 @@
 
 #define DDPM3D_CONV_CK 16      // input channels staged per LDS tile
 #define DDPM3D_REDUCE_VOX 16   // voxels per workgroup (= per statistics row) of the split-K reduce
-// split-f16 mode: activations are multiplied by this power of two before the hi/lo
-// split, each output channel's weights by 2^floor(log2(W_TARGET / max|w|)); the
-// epilogue multiplies by the exact inverse.  Keeps lo = x - f16(x) a NORMAL f16 for
-// all but negligibly small operands.
-#define DDPM3D_X3_ACT_SCALE 8.0f
+// split-f16 modes: each output channel's weights are multiplied by 2^floor(log2(W_TARGET / max|w|))
+// at pack time; the activations of a launch by the power of two that puts the caller's bound of
+// their magnitude just below 2^15 (ddpm3d_conv_desc.in_bound, act_scale() in conv3d_load.h); the
+// epilogue multiplies by the exact inverses.  Keeps lo = x - f16(x) a NORMAL f16 for all but
+// negligibly small operands and hi finite for EVERY input (no clamp anywhere).
 #define DDPM3D_X3_W_TARGET 8.0f
 
 struct ConvK {
@@ -26,7 +26,9 @@ struct ConvK {
     float* out;
     float* stats;
     float* partial;  // split-K slabs [ksplit][N*D*H*W][Cout], raw accumulators
-    const float* wscale;  // PREC 1: per-cout 1 / (activation scale * weight scale)
+    const float* wscale;  // split-f16 modes: per-cout 1 / weight scale
+    const float* in_bound;    // ddpm3d_conv_desc.in_bound (split-f16 modes)
+    int in_bound_count, in_bound_stride;
     unsigned w_bytes, src0_bytes, src1_bytes;  // extents for the buffer resource descriptors
     int N, D, H, W, Cin, Cout, C0, C1, CinPad, CoutPad;
     int in_mode, act, bias_stride_n, res_mode, out_layout, stats_rows;

@@ -14,7 +14,7 @@
 //   * out-of-volume (y, x) lanes never store: their LDS slots are zeroed once per workgroup (the
 //     tile column, hence the set of such lanes, is fixed); out-of-volume PLANES are a uniform skip;
 //   * "no activation" is exp2(-126) = 0 in the sigmoid's denominator instead of a per-value select;
-//   * the x8 pre-split scale is folded into the affine (exact: a power of two);
+//   * the pre-split power-of-two scale (act_scale(), conv3d_load.h) is folded into the affine (exact);
 //   * hi = cvt_pk(s), lo = cvt_pk(fma_mix(-hi + s)): 2 instructions per value instead of ~6;
 //   * scalar float code throughout (no f32x4 arithmetic: it lowers to v_pk_*_f32).
 // Value for value the arithmetic is the one of r01's staging (same roundings in the same order), so
@@ -53,21 +53,23 @@ struct StageLane {
     bool ok[WzGeom::NL];                         // slot exists and its (y, x) lies inside the volume
     unsigned plane0, plane1;                     // bytes per z-plane of src0 / src1
     int zb;                                      // first source plane the offsets refer to
-    float km, ka;                                // sigmoid exponent = fma(y8, km, ka)
+    float scale;                                 // activation scale S of this sample (power of two)
+    float km, ka;                                // sigmoid exponent = fma(yS, km, ka)
     int q;
 };
 
 // zb = the lowest input plane any item of this workgroup reads (clamped to 0)
-__device__ __forceinline__ StageLane stage_lane(const ConvK& p, int lt, int n, int y0, int x0, int zb) {
+__device__ __forceinline__ StageLane stage_lane(const ConvK& p, int lt, int n, int y0, int x0, int zb, float scale) {
     StageLane s;
+    s.scale = scale;
     const int up = p.in_mode == DDPM3D_IN_UP ? 1 : 0;
     const int Hs = p.H >> up, Ws = p.W >> up;
     s.q = lt & 3;
     s.zb = zb;
     s.plane0 = (unsigned)(Hs * Ws) * (unsigned)p.C0 * 4u;
     s.plane1 = (unsigned)(Hs * Ws) * (unsigned)p.C1 * 4u;
-    // act: e = exp2(-y log2e) with y8 = 8 y;  none: e = exp2(-126) ~ 1e-38, 1 + e == 1, y8 * 1 = y8
-    s.km = p.act ? -1.44269504088896341f / DDPM3D_X3_ACT_SCALE : 0.0f;
+    // act: e = exp2(-y log2e) with yS = S y;  none: e = exp2(-126) ~ 1e-38, 1 + e == 1, yS * 1 = yS
+    s.km = p.act ? -1.44269504088896341f / scale : 0.0f;
     s.ka = p.act ? 0.0f : -126.0f;
 #pragma unroll
     for (int i = 0; i < WzGeom::NL; ++i) {
@@ -147,20 +149,20 @@ __device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<
     float sa[4], sb[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        sa[c] = r.ga[c] * DDPM3D_X3_ACT_SCALE;
-        sb[c] = r.gb[c] * DDPM3D_X3_ACT_SCALE;
+        sa[c] = r.ga[c] * s.scale;
+        sb[c] = r.gb[c] * s.scale;
     }
 #pragma unroll
     for (int i = 0; i < WzGeom::NL; ++i) {
-        float d[NPL][4];   // 8 * act(A x + B) of the input planes
+        float d[NPL][4];   // S * act(A x + B) of the input planes
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             if (r.zmask & (1u << k)) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float y8 = __builtin_fmaf(r.v[i][k][c], sa[c], sb[c]);
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(y8, s.km, s.ka));
-                    d[k][c] = y8 * __builtin_amdgcn_rcpf(1.0f + e);
+                    const float ys = __builtin_fmaf(r.v[i][k][c], sa[c], sb[c]);
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(ys, s.km, s.ka));
+                    d[k][c] = ys * __builtin_amdgcn_rcpf(1.0f + e);
                 }
             } else {
 #pragma unroll
@@ -173,15 +175,13 @@ __device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int b = 2 * zp;
-                    float v[4];
+                    float v[4];   // |v| < 2^15 by the choice of S: nothing to clamp
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float t = j == 0 ? d[b][c] - d[b + 2][c]
-                                      : j == 1 ? d[b + 1][c] + d[b + 2][c]
-                                      : j == 2 ? d[b + 2][c] - d[b + 1][c]
-                                               : d[b + 1][c] - d[b + 3][c];
-                        v[c] = __builtin_amdgcn_fmed3f(t, -60000.0f, 60000.0f);
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        v[c] = j == 0 ? d[b][c] - d[b + 2][c]
+                             : j == 1 ? d[b + 1][c] + d[b + 2][c]
+                             : j == 2 ? d[b + 2][c] - d[b + 1][c]
+                                      : d[b + 1][c] - d[b + 3][c];
                     unsigned h0, h1, l0, l1;
                     split_pair(v[0], v[1], h0, l0);
                     split_pair(v[2], v[3], h1, l1);

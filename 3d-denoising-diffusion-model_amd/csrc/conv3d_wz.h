@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     const int chunk_begin = wg.split * p.chunks_per_split;
     const int chunk_end = min(nchunks, chunk_begin + p.chunks_per_split);
 
-    const StageLane sl = stage_lane(p, tid, n, y0, x0, max(z0 - 1, 0));
+    const ActScale asc = act_scale(p, n, 2.0f);   // the input transform adds two planes
+    const StageLane sl = stage_lane(p, tid, n, y0, x0, max(z0 - 1, 0), asc.s);
     stage_zero_border(sl, lds, 1, tid);
     StageRaw raw;
     if (chunk_begin < chunk_end) stage_issue(p, sl, raw, n, z0, chunk_begin);
@@ -159,5 +160,5 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         outv[2 + t] = acc[1][t] - acc[2][t] - acc[3][t];
     }
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<1, 1, 4, TXL, TYL>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split);
+    conv_epilogue<1, 1, 4, TXL, TYL>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split, asc.inv);
 }

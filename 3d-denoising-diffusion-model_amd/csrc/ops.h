@@ -7,7 +7,10 @@ hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, int pre
 hipError_t ddpm3d_launch_gn_finalize(const float* st0, int C0, int rows0, const float* st1, int C1,
                                      int rows1, int N, int groups, double count, float eps,
                                      const float* gamma, const float* beta, const float* film,
-                                     int film_stride, int film_off, float* A, float* B, hipStream_t st);
+                                     int film_stride, int film_off, float* A, float* B, float* bound,
+                                     hipStream_t st);
+hipError_t ddpm3d_launch_absmax(const float* x0, const float* x1, int N, size_t per_sample, float* bound,
+                                hipStream_t st);
 hipError_t ddpm3d_launch_gn_stats(const float* x, int N, int voxels, int C, float* stats, hipStream_t st);
 int ddpm3d_gn_stats_rows_impl(int voxels);
 hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, const float* freqs,
@@ -20,5 +23,6 @@ hipError_t ddpm3d_launch_subsample_hw2(const float* in, int N, int D, int H, int
 hipError_t ddpm3d_launch_sample_step(bool ddim, const float* mo, const float* x, const float* noise,
                                      const float* coef, const int64_t* t_idx, int N, int voxels, int flags,
                                      float eta, float* sample, float* pred_xstart, hipStream_t st);
-hipError_t ddpm3d_launch_attention(const float* qkv, int N, int T, int heads, int ch, int precision, float* out,
+hipError_t ddpm3d_launch_attention(const float* qkv, int N, int T, int heads, int ch, int precision,
+                                   const float* bound, int bound_count, int bound_stride, float* out,
                                    hipStream_t st);

@@ -27,7 +27,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Ci
 }
 
 // Split-f16 image.  Pass 1: per output channel, the power-of-two scale
-// s = 2^floor(log2(W_TARGET / max|w|)) and the epilogue factor 1 / (ACT_SCALE * s).
+// s = 2^floor(log2(W_TARGET / max|w|)) and the epilogue factor 1 / s.
 __global__ __launch_bounds__(256) void pack_x3_scale_kernel(const float* __restrict__ w, int Cout, int per_cout,
                                                             float* __restrict__ wscale) {
     const int co = blockIdx.x;
@@ -44,12 +44,12 @@ __global__ __launch_bounds__(256) void pack_x3_scale_kernel(const float* __restr
         float s = 1.0f;
         if (m > 0.0f && m < 3.0e38f) s = exp2f(floorf(log2f(DDPM3D_X3_W_TARGET / m)));
         s = fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
-        wscale[co] = 1.0f / (DDPM3D_X3_ACT_SCALE * s);  // exact: powers of two
+        wscale[co] = 1.0f / s;  // exact: powers of two
     }
 }
 
 // Pass 2: OIDHW -> [tap][ci/16][hi|lo][CoutPad][16 f16] of w * s[cout] (zero padded),
-// with s = 1 / (ACT_SCALE * wscale[cout]) recovered exactly from pass 1's output.
+// with s = 1 / wscale[cout] recovered exactly from pass 1's output.
 __global__ void pack_x3_kernel(const float* __restrict__ w, const float* __restrict__ wscale, int Cout,
                                int Cin, int taps, int CoutPad, int CinPad, _Float16* __restrict__ out) {
     const size_t total = (size_t)taps * CinPad * CoutPad;  // one (hi, lo) pair per element
@@ -63,7 +63,7 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, const float* __restr
         const int ci = cb * 16 + j;
         float v = 0.0f;
         if (co < Cout && ci < Cin)
-            v = w[((size_t)co * Cin + ci) * taps + tap] * (1.0f / (DDPM3D_X3_ACT_SCALE * wscale[co]));
+            v = w[((size_t)co * Cin + ci) * taps + tap] * (1.0f / wscale[co]);
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         const size_t base = (((size_t)tap * (CinPad / 16) + cb) * 2) * CoutPad * 16;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void pack_wz_scale_kernel(const float* __restr
         float s = 1.0f;
         if (m > 0.0f && m < 3.0e38f) s = exp2f(floorf(log2f(DDPM3D_X3_W_TARGET / m)));
         s = fminf(fmaxf(s, 1.0f / 16777216.0f), 16777216.0f);
-        wscale[co] = 1.0f / (DDPM3D_X3_ACT_SCALE * s);
+        wscale[co] = 1.0f / s;
     }
 }
 
@@ -118,7 +118,7 @@ __global__ void pack_wz_kernel(const float* __restrict__ w, const float* __restr
         const int ci = cb * 16 + jj;
         float v = 0.0f;
         if (co < Cout && ci < Cin)
-            v = wz_weight(w, (size_t)co * Cin + ci, tap / 9, tap % 9) * (1.0f / (DDPM3D_X3_ACT_SCALE * wscale[co]));
+            v = wz_weight(w, (size_t)co * Cin + ci, tap / 9, tap % 9) * (1.0f / wscale[co]);
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
         const size_t base = (((size_t)tap * (CinPad / 16) + cb) * 2) * CoutPad * 16;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const float* __restrict__ st0, int C0, int rows0, const float* __restrict__ st1, int C1, int rows1,
     int groups, double count, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ film, int film_stride, int film_off, float* __restrict__ A,
-    float* __restrict__ B) {
+    float* __restrict__ B, float* __restrict__ bound) {
     const int C = C0 + C1;
     const int cg = C / groups;
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
     // statistics are channel-major [N][C][rows][2]: the group's cg channels x rows partial sums
     // are ONE contiguous run of cg*rows float2, read with 16-byte loads
     double s1 = 0.0, s2 = 0.0;
+    float m2 = 0.0f;                                  // largest sum of squares of any row of the group
     const size_t items = (size_t)rows * cg;          // float2 count
     const float* run = st + ((size_t)n * Cs + cs) * rows * 2;
     if ((reinterpret_cast<uintptr_t>(run) & 15) == 0) {
@@ -203,32 +204,48 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
             const float4 v = *reinterpret_cast<const float4*>(run + i * 4);
             s1 += (double)v.x + (double)v.z;
             s2 += (double)v.y + (double)v.w;
+            m2 = fmaxf(m2, fmaxf(v.y, v.w));
         }
         if ((items & 1) && threadIdx.x == 0) {
             s1 += (double)run[(items - 1) * 2];
             s2 += (double)run[(items - 1) * 2 + 1];
+            m2 = fmaxf(m2, run[(items - 1) * 2 + 1]);
         }
     } else {                                         // odd rows x odd channel offset: 8-byte aligned only
         for (size_t i = threadIdx.x; i < items; i += blockDim.x) {
             const float2 v = *reinterpret_cast<const float2*>(run + i * 2);
             s1 += (double)v.x;
             s2 += (double)v.y;
+            m2 = fmaxf(m2, v.y);
         }
     }
     __shared__ double red[2][4];
+    __shared__ float redm[4], redab[2][4];
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o));
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = s1; red[1][wave] = s2; redm[wave] = m2; }
     __syncthreads();
     s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
     s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    // every |x| of the group is at most the square root of the largest row's sum of squares
+    const float xmax = sqrtf(fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])));
+    if (gamma == nullptr) {                          // bounds only (tensor consumed without a GroupNorm)
+        if (threadIdx.x == 0 && bound != nullptr) {
+            bound[(size_t)blockIdx.x * 2] = xmax;
+            bound[(size_t)blockIdx.x * 2 + 1] = xmax;
+        }
+        return;
+    }
     const double cnt = count * cg;
     const double mean = s1 / cnt;
     double var = s2 / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float meanf = (float)mean;
+    float amax = 0.0f, bmax = 0.0f;
     for (int c = threadIdx.x; c < cg; c += blockDim.x) {
         const int ch = cbeg + c;
         float a = rstd * gamma[ch];
@@ -241,15 +258,64 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
         }
         A[(size_t)n * C + ch] = a;
         B[(size_t)n * C + ch] = b;
+        amax = fmaxf(amax, fabsf(a));
+        bmax = fmaxf(bmax, fabsf(b));
     }
+    if (bound != nullptr) {
+        // |act(a x + b)| <= |a| xmax + |b| for act = identity or SiLU
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            amax = fmaxf(amax, __shfl_xor(amax, o));
+            bmax = fmaxf(bmax, __shfl_xor(bmax, o));
+        }
+        if ((threadIdx.x & 63) == 0) { redab[0][wave] = amax; redab[1][wave] = bmax; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            amax = fmaxf(fmaxf(redab[0][0], redab[0][1]), fmaxf(redab[0][2], redab[0][3]));
+            bmax = fmaxf(fmaxf(redab[1][0], redab[1][1]), fmaxf(redab[1][2], redab[1][3]));
+            bound[(size_t)blockIdx.x * 2] = fmaf(amax, xmax, bmax);
+            bound[(size_t)blockIdx.x * 2 + 1] = xmax;
+        }
+    }
+}
+
+// max |x| per sample of up to two tensors: bound[n * count + t]
+__global__ __launch_bounds__(1024) void absmax_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                      size_t per_sample, int count, float* __restrict__ bound) {
+    const int n = blockIdx.x / count, t = blockIdx.x % count;
+    const float* x = (t == 0 ? x0 : x1) + (size_t)n * per_sample;
+    float m = 0.0f;
+    const size_t quads = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? per_sample / 4 : 0;
+    for (size_t i = threadIdx.x; i < quads; i += blockDim.x) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (size_t i = quads * 4 + threadIdx.x; i < per_sample; i += blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float red[16];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+        bound[blockIdx.x] = m;
+    }
+}
+
+hipError_t ddpm3d_launch_absmax(const float* x0, const float* x1, int N, size_t per_sample, float* bound,
+                                hipStream_t st) {
+    const int count = x1 ? 2 : 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3(N * count), dim3(1024), 0, st, x0, x1, per_sample, count, bound);
+    return hipGetLastError();
 }
 
 hipError_t ddpm3d_launch_gn_finalize(const float* st0, int C0, int rows0, const float* st1, int C1,
                                      int rows1, int N, int groups, double count, float eps,
                                      const float* gamma, const float* beta, const float* film,
-                                     int film_stride, int film_off, float* A, float* B, hipStream_t st) {
+                                     int film_stride, int film_off, float* A, float* B, float* bound,
+                                     hipStream_t st) {
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, st, st0, C0, rows0, st1, C1,
-                       rows1, groups, count, eps, gamma, beta, film, film_stride, film_off, A, B);
+                       rows1, groups, count, eps, gamma, beta, film, film_stride, film_off, A, B, bound);
     return hipGetLastError();
 }
 

@@ -42,7 +42,8 @@ class ConvDesc(C.Structure):
         ("w_packed", _fp), ("bias", _fp), ("bias_stride_n", C.c_int32), ("res_mode", C.c_int32),
         ("res", _fp), ("out", _fp), ("out_layout", C.c_int32), ("stats_rows", C.c_int32),
         ("stats", _fp), ("workspace", _fp), ("workspace_bytes", C.c_size_t),
-        ("kernel_hint", C.c_int32), ("reserved0", C.c_int32),
+        ("kernel_hint", C.c_int32), ("in_bound_count", C.c_int32), ("in_bound", _fp),
+        ("in_bound_stride", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -56,13 +57,15 @@ EXPORTS = {
     "ddpm3d_conv_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
     "ddpm3d_conv3d": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "ddpm3d_gn_finalize": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_double, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp]),
+                                     C.c_double, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+    "ddpm3d_absmax": (C.c_int, [_fp, _fp, C.c_int, C.c_size_t, _fp, _fp]),
     "ddpm3d_gn_stats_rows": (C.c_int, [C.c_int]),
     "ddpm3d_gn_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_timestep_embedding": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ddpm3d_linear": (C.c_int, [_fp, C.c_int, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp, C.c_int, _fp]),
     "ddpm3d_attention": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
-    "ddpm3d_attention_p": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ddpm3d_attention_p": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.c_int,
+                                     _fp, _fp]),
     "ddpm3d_ncdhw_to_ndhwc": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_ndhwc_to_ncdhw": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_subsample_hw2": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),

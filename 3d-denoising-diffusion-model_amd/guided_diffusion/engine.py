@@ -206,7 +206,11 @@ class _Plan:
         cin_conv = eng.conv[first.prefix]
         self.first_desc = None
         h = new_act(cin_conv.Cout, D, Hh, W)
-        self.first_desc = self.conv_step(cin_conv, srcs=None, out=h, planar=True)
+        # range of the two input volumes (they carry no statistics): [N][2] = max |x|, max |low_res|
+        self.in_absmax = torch.empty(N * 2, dtype=torch.float32, device=dev)
+        self.absmax_args = [0, 0, N, D * Hh * W, H.ptr(self.in_absmax), 0]
+        self.steps.append((lib.ddpm3d_absmax, self.absmax_args))
+        self.first_desc = self.conv_step(cin_conv, srcs=None, out=h, planar=True, bound=(self.in_absmax, 0, 2, 1))
         hs = [h]
         for blk in topo.input[1:]:
             for i, e in enumerate(blk):
@@ -227,12 +231,12 @@ class _Plan:
                     release(a)
                 srcs = [h]
         # out: GN -> SiLU -> conv, stored NCDHW
-        A, B = self.finalize([h], "out.0", None)
+        A, B, bnd = self.finalize([h], "out.0", None)
         oc = eng.conv["out.2"]
         self.out_C = oc.Cout
         self.out_shape = (N, oc.Cout, D, Hh, W)
         self.out_buf = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
-        self.last_desc = self.conv_step(oc, srcs=[h], out=None, aff=(A, B), act=H.ACT_SILU,
+        self.last_desc = self.conv_step(oc, srcs=[h], out=None, aff=(A, B), act=H.ACT_SILU, bound=(bnd, 0, 32, 2),
                                         out_tensor=self.out_buf, out_layout=H.OUT_NCDHW)
         release(h)
         # one split-K scratch buffer shared by every conv of the plan (they run in stream order)
@@ -243,31 +247,35 @@ class _Plan:
 
     # ---- helpers -------------------------------------------------------------
     def finalize(self, srcs, gn_prefix, film_prefix):
-        """gn_finalize over the virtual concat of `srcs`; returns (A, B) tensors."""
+        """gn_finalize over the virtual concat of `srcs`; returns (A, B, bound) tensors.  bound =
+        [N][32][2]: upper bounds of |act(A*x + B)| (entry 0) and of |x| (entry 1) per group, the
+        in_bound of the convs that read the tensor normalised / raw.  gn_prefix None: bounds only."""
         eng, N = self.eng, self.N
         Cn = sum(s.C for s in srcs)
-        A = torch.empty(N * Cn, dtype=torch.float32, device=eng.device)
-        B = torch.empty(N * Cn, dtype=torch.float32, device=eng.device)
+        A = torch.empty(N * Cn, dtype=torch.float32, device=eng.device) if gn_prefix else None
+        B = torch.empty(N * Cn, dtype=torch.float32, device=eng.device) if gn_prefix else None
+        bound = torch.empty(N * 32 * 2, dtype=torch.float32, device=eng.device)
         s0 = srcs[0]
         s1 = srcs[1] if len(srcs) > 1 else None
         if s1 is not None and s1.voxels != s0.voxels:
             raise RuntimeError("concat of tensors with different spatial size")
-        gamma = eng.p[gn_prefix + ".weight"]
-        beta = eng.p[gn_prefix + ".bias"]
+        gamma = eng.p[gn_prefix + ".weight"] if gn_prefix else None
+        beta = eng.p[gn_prefix + ".bias"] if gn_prefix else None
         args = [H.ptr(s0.stats), s0.C, s0.rows,
                 H.ptr(s1.stats) if s1 else 0, s1.C if s1 else 0, s1.rows if s1 else 0,
                 N, 32, float(s0.voxels), 1e-5, H.ptr(gamma), H.ptr(beta),
-                0, 0, 0, H.ptr(A), H.ptr(B), 0]
+                0, 0, 0, H.ptr(A), H.ptr(B), H.ptr(bound), 0]
         if film_prefix is not None:
             args[14] = eng.film_off[film_prefix]
             self.film_patches.append(args)
         self.steps.append((eng.lib.ddpm3d_gn_finalize, args))
-        self.keep += [A, B]
-        return A, B
+        self.keep += [A, B, bound]
+        return A, B, bound
 
     def conv_step(self, pc, srcs, out, aff=None, act=H.ACT_NONE, in_mode=H.IN_SAME, res=None,
                   res_mode=H.RES_NONE, planar=False, out_tensor=None, out_layout=H.OUT_NDHWC,
-                  bias_per_n=False, want_stats=True):
+                  bias_per_n=False, want_stats=True, bound=None):
+        """bound = (tensor, first entry, entries per sample, stride): ddpm3d_conv_desc.in_bound"""
         N = self.N
         d = H.ConvDesc()
         lib = self.eng.lib
@@ -302,6 +310,10 @@ class _Plan:
         if aff is not None:
             d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
         d.act = act
+        if bound is None:
+            raise RuntimeError("conv_step without an input bound")
+        d.in_bound = bound[0].data_ptr() + 4 * bound[1]
+        d.in_bound_count, d.in_bound_stride = bound[2], bound[3]
         if (pc.wz is not None and not planar and in_mode in (H.IN_SAME, H.IN_UP)
                 and d.H >= 8 and d.W >= 8):
             pc_use = pc.wz       # Winograd-D form: same layer, same arithmetic, 2/3 of the MFMAs
@@ -338,7 +350,8 @@ class _Plan:
             x = srcs[0]
             pc = eng.conv[e.prefix + ".conv"]
             y = self.new_act(pc.Cout, x.D, x.H * 2, x.W * 2)
-            self.conv_step(pc, [x], y, in_mode=H.IN_UP)
+            _, _, bnd = self.finalize([x], None, None)
+            self.conv_step(pc, [x], y, in_mode=H.IN_UP, bound=(bnd, 1, 32, 2))
             return y
         if e.kind == "attn":
             return self.attention(e, srcs[0])
@@ -353,7 +366,8 @@ class _Plan:
             pc = eng.conv[e.prefix + ".op"]
             lib, N = eng.lib, self.N
             full = self.new_act(pc.Cout, x.D, x.H, x.W)
-            self.conv_step(pc, [x], full, want_stats=False)
+            _, _, bnd = self.finalize([x], None, None)
+            self.conv_step(pc, [x], full, want_stats=False, bound=(bnd, 1, 32, 2))
             y = self.new_act(pc.Cout, x.D, x.H // 2, x.W // 2)
             self.steps.append((lib.ddpm3d_subsample_hw2,
                                [H.ptr(full.buf), N, x.D, x.H, x.W, pc.Cout, H.ptr(y.buf), 0]))
@@ -378,9 +392,12 @@ class _Plan:
         ch = Cn // heads
         if ch not in (32, 64, 128):
             raise NotImplementedError("attention with %d channels per head (32, 64 or 128 are built)" % ch)
-        A, B = self.finalize([x], p + ".norm", None)
+        A, B, bnd = self.finalize([x], p + ".norm", None)
         qkv = self.new_act(3 * Cn, x.D, x.H, x.W)
-        self.conv_step(eng.conv[p + ".qkv"], [x], qkv, aff=(A, B), act=H.ACT_NONE, want_stats=False)
+        self.conv_step(eng.conv[p + ".qkv"], [x], qkv, aff=(A, B), act=H.ACT_NONE, bound=(bnd, 0, 32, 2))
+        # range of q, k, v (and of the attention output, a convex combination of v) from qkv's
+        # own partial sums
+        _, _, qb = self.finalize([qkv], None, None)
         a = self.new_act(Cn, x.D, x.H, x.W)
         # two T x T x ch products per head (the reference's count_flops_attn, unet.py:308-325)
         self.conv_meta[len(self.steps)] = ("attention_ch%d" % ch, 4.0 * N * heads * float(x.voxels) ** 2 * ch)
@@ -389,10 +406,10 @@ class _Plan:
         # fp32 (unet.py:351), and f16-rounded scores would cost more accuracy than the convs do)
         aprec = H.PREC_F32 if eng.precision == "f32" else H.PREC_F16X3
         self.steps.append((eng.lib.ddpm3d_attention_p,
-                           [H.ptr(qkv.buf), N, x.voxels, heads, ch, aprec, H.ptr(a.buf), 0]))
+                           [H.ptr(qkv.buf), N, x.voxels, heads, ch, aprec, H.ptr(qb) + 4, 32, 2, H.ptr(a.buf), 0]))
         self.release(qkv)
         y = self.new_act(Cn, x.D, x.H, x.W)
-        self.conv_step(eng.conv[p + ".proj_out"], [a], y, res=x, res_mode=H.RES_SAME)
+        self.conv_step(eng.conv[p + ".proj_out"], [a], y, res=x, res_mode=H.RES_SAME, bound=(qb, 1, 32, 2))
         self.release(a)
         return y
 
@@ -410,23 +427,27 @@ class _Plan:
             d, h, w, im, rm = x0.D, x0.H, x0.W, H.IN_SAME, H.RES_SAME
         c1 = eng.conv[p + ".in_layers.2"]
         c2 = eng.conv[p + ".out_layers.3"]
-        A1, B1 = self.finalize(srcs, p + ".in_layers.0", None)
+        A1, B1, bnd1 = self.finalize(srcs, p + ".in_layers.0", None)
         h1 = self.new_act(c1.Cout, d, h, w)
         if eng.film:
-            self.conv_step(c1, srcs, h1, aff=(A1, B1), act=H.ACT_SILU, in_mode=im)
-            A2, B2 = self.finalize([h1], p + ".out_layers.0", p)
+            self.conv_step(c1, srcs, h1, aff=(A1, B1), act=H.ACT_SILU, in_mode=im, bound=(bnd1, 0, 32, 2))
+            A2, B2, bnd2 = self.finalize([h1], p + ".out_layers.0", p)
         else:
             # additive embedding: conv1's bias is the per-sample film row slice
-            dsc = self.conv_step(c1, srcs, h1, aff=(A1, B1), act=H.ACT_SILU, in_mode=im, bias_per_n=True)
+            dsc = self.conv_step(c1, srcs, h1, aff=(A1, B1), act=H.ACT_SILU, in_mode=im, bias_per_n=True,
+                                 bound=(bnd1, 0, 32, 2))
             self.bias_patches.append((dsc, eng.film_off[p]))
-            A2, B2 = self.finalize([h1], p + ".out_layers.0", None)
+            A2, B2, bnd2 = self.finalize([h1], p + ".out_layers.0", None)
         y = self.new_act(c2.Cout, d, h, w)
         skip = eng.conv.get(p + ".skip_connection")
         if skip is not None:
             if e.updown is not None:
                 raise RuntimeError("up/down ResBlock with a channel change is not in the reference")
-            self.conv_step(skip, srcs, y, want_stats=False)   # y = skip(x), then accumulated into
-            self.conv_step(c2, [h1], y, aff=(A2, B2), act=H.ACT_SILU, res=y, res_mode=H.RES_SAME)
+            # y = skip(x) on the RAW block input (its range: entry 1 of the same finalize), then
+            # accumulated into
+            self.conv_step(skip, srcs, y, want_stats=False, bound=(bnd1, 1, 32, 2))
+            self.conv_step(c2, [h1], y, aff=(A2, B2), act=H.ACT_SILU, res=y, res_mode=H.RES_SAME,
+                           bound=(bnd2, 0, 32, 2))
         else:
             if len(srcs) > 1:
                 # Identity skip over the decoder's virtual concat [h, skip] (2*inch == outch, e.g. a
@@ -434,7 +455,7 @@ class _Plan:
                 # concatenation itself, which no epilogue mode reads.
                 raise NotImplementedError("ResBlock with an Identity skip over a concatenated input "
                                           "(%d + %d -> %d channels)" % (srcs[0].C, srcs[1].C, c2.Cout))
-            self.conv_step(c2, [h1], y, aff=(A2, B2), act=H.ACT_SILU, res=x0, res_mode=rm)
+            self.conv_step(c2, [h1], y, aff=(A2, B2), act=H.ACT_SILU, res=x0, res_mode=rm, bound=(bnd2, 0, 32, 2))
         self.release(h1)
         return y
 
@@ -445,6 +466,7 @@ class _Plan:
         st = H.stream()
         self.first_desc.src0 = x.data_ptr()
         self.first_desc.src1 = low_res.data_ptr()
+        self.absmax_args[0], self.absmax_args[1] = x.data_ptr(), low_res.data_ptr()
         fptr = film_rows.data_ptr()
         for a in self.film_patches:
             a[12], a[13] = fptr, film_stride

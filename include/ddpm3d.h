@@ -118,6 +118,18 @@ typedef struct ddpm3d_conv_desc {
      * launch orders of IDENTICAL arithmetic (bit-identical outputs); they exist for tests and A/B
      * measurements and never change a result. */
     int32_t kernel_hint;
+    /* Range of the convolution's INPUT as the matrix cores see it, for the split-f16 modes (every
+     * precision but DDPM3D_PREC_F32, which ignores it; REQUIRED otherwise).  Sample n's entries
+     * in_bound[(n * in_bound_count + i) * in_bound_stride], i < in_bound_count <= 64, are upper
+     * bounds of |act(A*x + B)| over (parts of) that sample's input; the kernel takes their maximum b
+     * and scales the activations by the power of two that puts b just below 2^15 before the f16
+     * hi/lo split (the epilogue multiplies by the exact inverse).  So no input magnitude is clipped
+     * and small-magnitude tensors keep their low bits; a bound that is too SMALL makes f16 overflow
+     * and the output non-finite (never silently wrong).  Producers: ddpm3d_gn_finalize (normalised
+     * and raw bounds from the GroupNorm partial sums), ddpm3d_absmax (tensors without statistics). */
+    int32_t in_bound_count;
+    const float* in_bound;
+    int32_t in_bound_stride;
     int32_t reserved0;
 } ddpm3d_conv_desc;
 
@@ -186,7 +198,19 @@ int ddpm3d_gn_finalize(const float* stats0, int C0, int rows0,
                        int N, int groups, double count, float eps,
                        const float* gamma, const float* beta,
                        const float* film, int film_stride, int film_off,
-                       float* aff_a, float* aff_b, void* stream);
+                       float* aff_a, float* aff_b, float* bound, void* stream);
+/* `bound` (may be NULL) = [N][groups][2] upper bounds for ddpm3d_conv_desc.in_bound, from the same
+ * partial sums: a value of channel c is at most xmax = sqrt(largest sum of squares of any statistics
+ * row of its group), so
+ *   bound[n][g][0] = max_c |A[n][c]| * xmax + max_c |B[n][c]|   >= |act(A*x + B)|  (|SiLU(y)| <= |y|)
+ *   bound[n][g][1] = xmax                                       >= |x|  (the tensor read raw)
+ * gamma == NULL (then beta, film, aff_a, aff_b are ignored): bounds only, for tensors that are
+ * consumed without a GroupNorm. */
+
+/* bound[n * count + t] = max |x| over sample n of tensor t, for up to two tensors of `per_sample`
+ * floats per sample (count = 1 or 2; x1 may be NULL): ddpm3d_conv_desc.in_bound of inputs that have
+ * no statistics (the first conv's x and low_res volumes, attention outputs). */
+int ddpm3d_absmax(const float* x0, const float* x1, int N, size_t per_sample, float* bound, void* stream);
 
 /* partial sums of an NDHWC tensor that no conv epilogue produced;
  * stats [N][C][rows][2] with rows = ddpm3d_gn_stats_rows(voxels) */
@@ -218,7 +242,10 @@ int ddpm3d_attention(const float* qkv, int N, int T, int heads, int head_channel
  * on hi/lo-split q, k, v and softmax weights; 16/3 of the fp32 MFMA rate).  The softmax itself is
  * fp32 in both (unet.py:351). */
 int ddpm3d_attention_p(const float* qkv, int N, int T, int heads, int head_channels, int precision,
+                       const float* qkv_bound, int bound_count, int bound_stride,
                        float* out, void* stream);
+/* qkv_bound: as ddpm3d_conv_desc.in_bound, upper bounds of |qkv| per sample (required for
+ * DDPM3D_PREC_F16X3, ignored for DDPM3D_PREC_F32). */
 
 /* layout changes at the API edge */
 int ddpm3d_ncdhw_to_ndhwc(const float* in, int N, int C, int voxels, float* out, void* stream);

@@ -27,8 +27,11 @@ def pack(w, precision=0):
 
 
 def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res=None, res_mode=H.RES_NONE,
-           out_layout=H.OUT_NDHWC, want_stats=True, planar=False, bias_stride_n=0, precision=0, hint=0):
+           out_layout=H.OUT_NDHWC, want_stats=True, planar=False, bias_stride_n=0, precision=0, hint=0,
+           bound=None):
     """srcs: list of NDHWC device tensors (or two (N,1,D,H,W) volumes when planar).
+    bound: [N, k] device tensor of upper bounds of the input as the matrix cores see it
+    (ddpm3d_conv_desc.in_bound); default = the exact maximum of |act(A*x + B)| per sample.
     Returns (out, stats, rows)."""
     lib = H.load()
     dev = w.device
@@ -52,6 +55,19 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
     d.act = act
     d.precision = precision
     d.kernel_hint = hint
+    if bound is None:
+        with torch.no_grad():
+            if planar:
+                xin = torch.stack([srcs[0].reshape(N, -1), srcs[1].reshape(N, -1)], dim=-1)
+            else:
+                xin = torch.cat([s.reshape(N, -1, s.shape[-1]) for s in srcs], dim=-1)
+            if aff is not None:
+                xin = xin * aff[0].reshape(N, 1, -1) + aff[1].reshape(N, 1, -1)
+                if act == H.ACT_SILU:
+                    xin = torch.nn.functional.silu(xin)
+            bound = xin.abs().reshape(N, -1).amax(dim=1, keepdim=True).contiguous()
+    bound = bound.float().contiguous()
+    d.in_bound, d.in_bound_count, d.in_bound_stride = H.ptr(bound), bound.shape[1], 1
     wp = pack(w, precision)
     d.w_packed, d.bias, d.bias_stride_n = H.ptr(wp), H.ptr(b), bias_stride_n
     d.res_mode, d.res = res_mode, H.ptr(res)
@@ -74,7 +90,8 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
     return out, stats, rows
 
 
-def gn_finalize(stats_list, count, gamma, beta, film=None, film_stride=0, film_off=0, groups=32):
+def gn_finalize(stats_list, count, gamma, beta, film=None, film_stride=0, film_off=0, groups=32,
+                with_bound=False):
     lib = H.load()
     s0 = stats_list[0]
     s1 = stats_list[1] if len(stats_list) > 1 else None
@@ -82,13 +99,15 @@ def gn_finalize(stats_list, count, gamma, beta, film=None, film_stride=0, film_o
     Cn = s0.shape[1] + (s1.shape[1] if s1 is not None else 0)
     A = torch.empty(N, Cn, dtype=torch.float32, device=s0.device)
     B = torch.empty(N, Cn, dtype=torch.float32, device=s0.device)
+    bound = torch.full((N, groups, 2), float("nan"), dtype=torch.float32, device=s0.device)
     H.check(lib.ddpm3d_gn_finalize(H.ptr(s0), s0.shape[1], s0.shape[2],
                                    H.ptr(s1), s1.shape[1] if s1 is not None else 0,
                                    s1.shape[2] if s1 is not None else 0,
                                    N, groups, float(count), 1e-5, H.ptr(gamma), H.ptr(beta),
-                                   H.ptr(film), film_stride, film_off, H.ptr(A), H.ptr(B), H.stream()))
+                                   H.ptr(film), film_stride, film_off, H.ptr(A), H.ptr(B), H.ptr(bound),
+                                   H.stream()))
     torch.cuda.synchronize()
-    return A, B
+    return (A, B, bound) if with_bound else (A, B)
 
 
 def gn_stats(x_ndhwc):

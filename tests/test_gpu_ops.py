@@ -410,7 +410,8 @@ def test_attention_core_vs_legacy_reference(hc, N, T, heads, ch, scale, precisio
     ref = torch.einsum("bts,bcs->bct", w, v).reshape(N, -1, T)    # (N, H*C, T)
     qd = qkv.permute(0, 2, 1).contiguous().cuda()                 # channels-last (N, T, H*3*C)
     out = torch.full((N, T, heads * ch), float("nan"), device="cuda")
-    H.check(lib.ddpm3d_attention_p(H.ptr(qd), N, T, heads, ch, precision, H.ptr(out), H.stream()))
+    qb = qd.abs().reshape(N, -1).amax(dim=1).contiguous()          # per-sample range of q, k, v
+    H.check(lib.ddpm3d_attention_p(H.ptr(qd), N, T, heads, ch, precision, H.ptr(qb), 1, 1, H.ptr(out), H.stream()))
     torch.cuda.synchronize()
     assert rel_err(out.permute(0, 2, 1).cpu().numpy(), ref.double().numpy()) < 1e-5
     if precision == 0:      # the two-argument entry point is the exact mode
