@@ -20,15 +20,18 @@ import torch
 import torch.distributed as dist
 
 
-def setup_dist(backend=None, init_method=None):
+def setup_dist(backend=None, init_method=None, share_gpu=False):
     """Initialise the default process group from the torchrun environment
     (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT; or an explicit
     `init_method` such as file://...).  A single process (WORLD_SIZE unset or 1)
-    needs no group, like dist_util.py:29-31."""
+    needs no group, like dist_util.py:29-31.
+    share_gpu: every rank computes on cuda:0 (rehearsal of the multi-rank flow on a
+    one-GPU box; needs backend "gloo" -- RCCL refuses two ranks on one device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1 or dist.is_initialized():
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(local)
         return
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (required on this stack)
@@ -38,10 +41,13 @@ def setup_dist(backend=None, init_method=None):
     if init_method is not None:
         extra = dict(init_method=init_method, rank=int(os.environ["RANK"]), world_size=world)
     if backend == "nccl":
-        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if share_gpu:
+            raise RuntimeError("share_gpu needs the gloo backend")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local), **extra)
     else:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
         dist.init_process_group(backend, **extra)
 
 
@@ -91,6 +97,8 @@ def gather_round(sample, index):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [] if index is None else [(index, sample)]
     world = dist.get_world_size()
+    if dist.get_backend() == "gloo":
+        sample = sample.cpu()                  # gloo collectives run through host memory
     idx = torch.tensor([-1 if index is None else index], dtype=torch.int64, device=sample.device)
     idxs = [torch.empty_like(idx) for _ in range(world)]
     outs = [torch.empty_like(sample) for _ in range(world)]

@@ -39,7 +39,10 @@ from guided_diffusion.script_util import (
 
 def create_argparser():
     defaults = dict(save_dir="", clip_denoised=True, batch_size=1, use_ddim=False, eta=0.0,
-                    timestep_respacing="", base_samples="", model_path="")
+                    timestep_respacing="", base_samples="", model_path="",
+                    # launch-side extras (not in the reference): collective backend ("" = RCCL on
+                    # GPUs) and all ranks on cuda:0, to rehearse the multi-rank flow on a one-GPU box
+                    dist_backend="", share_gpu=False)
     defaults.update(sr_model_and_diffusion_defaults())
     parser = argparse.ArgumentParser()
     add_dict_to_argparser(parser, defaults)
@@ -48,7 +51,7 @@ def create_argparser():
 
 def main(argv=None):
     args = create_argparser().parse_args(argv)
-    dist_util.setup_dist()
+    dist_util.setup_dist(backend=args.dist_backend or None, share_gpu=args.share_gpu)
     logger.configure(dir=args.save_dir)
     dev = dist_util.dev()
 
