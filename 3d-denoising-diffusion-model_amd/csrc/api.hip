@@ -28,8 +28,10 @@ extern "C" {
 int ddpm3d_abi_version(void) { return DDPM3D_ABI_VERSION; }
 const char* ddpm3d_last_error(void) { return g_err; }
 
-static bool prec_ok(int p) { return p >= DDPM3D_PREC_F32 && p <= DDPM3D_PREC_F16_WZ; }
-static bool prec_wz(int p) { return p == DDPM3D_PREC_F16X3_WZ || p == DDPM3D_PREC_F16_WZ; }
+static bool prec_ok(int p) { return p >= DDPM3D_PREC_F32 && p <= DDPM3D_PREC_BF16_WZ; }
+static bool prec_wz(int p) { return p == DDPM3D_PREC_F16X3_WZ || p == DDPM3D_PREC_F16_WZ || p == DDPM3D_PREC_BF16_WZ; }
+// modes whose activation scale comes from in_bound (the bf16 modes need none: fp32's exponent range)
+static bool prec_scaled(int p) { return p != DDPM3D_PREC_F32 && p != DDPM3D_PREC_BF16 && p != DDPM3D_PREC_BF16_WZ; }
 
 // the Winograd-D form exists for 3x3x3 layers whose couts fill whole 128-wide workgroups
 static bool wz_layer_ok(int Cout, int Cin, int ksize) {
@@ -123,7 +125,14 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     k.stats_rows = c.stats_rows;
     k.reduce_vox = c.reduce_vox;
     k.hint = d->kernel_hint;
-    if (d->precision != DDPM3D_PREC_F32) {
+    k.io = d->io_dtype;
+    if (d->io_dtype & ~(DDPM3D_IO_SRC0_BF16 | DDPM3D_IO_SRC1_BF16 | DDPM3D_IO_OUT_BF16 | DDPM3D_IO_RES_BF16))
+        return fail(DDPM3D_EINVAL, "conv3d: unknown io_dtype bits %#x", d->io_dtype);
+    if ((d->io_dtype & DDPM3D_IO_OUT_BF16) && d->out_layout != DDPM3D_OUT_NDHWC)
+        return fail(DDPM3D_EINVAL, "conv3d: a bf16 output needs the NDHWC layout");
+    if ((d->io_dtype & (DDPM3D_IO_SRC0_BF16 | DDPM3D_IO_SRC1_BF16)) && d->in_mode == DDPM3D_IN_PLANAR2)
+        return fail(DDPM3D_EINVAL, "conv3d: the planar input volumes are fp32");
+    if (prec_scaled(d->precision)) {
         if (!d->in_bound || d->in_bound_count <= 0 || d->in_bound_count > 64 || d->in_bound_stride <= 0)
             return fail(DDPM3D_EINVAL, "conv3d: the split-f16 precisions need in_bound (1..64 entries per sample): "
                                        "the activation scale is derived from it, nothing is clamped");
@@ -139,7 +148,8 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         const long long Hs = d->in_mode == DDPM3D_IN_POOL ? 2LL * d->H : (d->in_mode == DDPM3D_IN_UP ? d->H / 2 : d->H);
         const long long Ws = d->in_mode == DDPM3D_IN_POOL ? 2LL * d->W : (d->in_mode == DDPM3D_IN_UP ? d->W / 2 : d->W);
         const long long vox = (long long)d->N * d->D * Hs * Ws;
-        const long long b0 = vox * d->C0 * 4, b1 = vox * d->C1 * 4;
+        const long long b0 = vox * d->C0 * ((d->io_dtype & DDPM3D_IO_SRC0_BF16) ? 2 : 4);
+        const long long b1 = vox * d->C1 * ((d->io_dtype & DDPM3D_IO_SRC1_BF16) ? 2 : 4);
         const size_t wb = ddpm3d_packed_bytes(d->Cout, d->Cin, d->ksize, d->precision);
         if (b0 >= 0xFFFFFFF0LL || b1 >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0ULL)
             return fail(DDPM3D_EINVAL, "conv3d: a source tensor or the weights exceed 4 GiB; split the batch");

@@ -28,6 +28,7 @@
 //           accumulation error both modes share -- at 16/3 the MFMA rate.
 //   PREC 2  one product on the hi halves only (operands rounded to f16): the reference's
 //           --use_fp16 analogue.
+//   PREC 5  one bf16 MFMA per product (operands rounded to bf16, no scaling): BASELINE config 4.
 //
 // K order inside a channel block is permuted in PREC 0 (lane half h supplies
 // channel 4h+s at step s) so both operands are 16-byte loads; the weight packer
@@ -121,9 +122,9 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
     const int q = tid % QPV;  // fixed per thread: 256 % QPV == 0
     const int up_shift = p.in_mode == DDPM3D_IN_UP ? 1 : 0;
     const unsigned act_mask = p.act ? 0xFFFFFFFFu : 0u;
-    f32x4 raw[PIPE ? NL : 1];
+    u32x4 raw[PIPE ? NL : 1];   // raw bits of the prefetched quads (fp32, or bf16 in the low half)
     ActScale asc = {1.0f, 1.0f};
-    if constexpr (PREC != 0) asc = act_scale(p, n, 1.0f);
+    if constexpr (PREC == 1 || PREC == 2) asc = act_scale(p, n, 1.0f);
     HaloSrc hs = halo_src<CK>(p, n, chunk_begin < chunk_end ? chunk_begin : 0, q);
     // source voxel of each staging item (-1 = zero padding): launch-invariant, one VGPR each
     int vox[PIPE ? NL : 1];
@@ -140,12 +141,13 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
     }
     auto issue_raw = [&](const HaloSrc& h) {
         const __amdgpu_buffer_rsrc_t srsrc = make_rsrc(h.src, h.src_bytes);  // uniform: src0 or src1
-        const unsigned row_bytes = (unsigned)h.Cs * 4, soff = (unsigned)h.cb * 4;
+        const unsigned es = h.b16 ? 2u : 4u;                                 // bytes per element
+        const unsigned row_bytes = (unsigned)h.Cs * es, soff = (unsigned)h.cb * es;
 #pragma unroll
         for (int i = 0; i < (PIPE ? NL : 0); ++i) {
             // out-of-range offset -> the buffer load returns 0 = the conv's zero padding
-            const unsigned voff = vox[i] < 0 ? DDPM3D_OOB_OFFSET : (unsigned)vox[i] * row_bytes + q * 16;
-            raw[i] = __builtin_bit_cast(f32x4, buffer_load16(srsrc, voff, soff));
+            const unsigned voff = vox[i] < 0 ? DDPM3D_OOB_OFFSET : (unsigned)vox[i] * row_bytes + q * 4 * es;
+            raw[i] = buffer_load_quad(srsrc, voff, soff, h.b16);
         }
     };
     if (PIPE && chunk_begin < chunk_end) issue_raw(hs);
@@ -163,6 +165,8 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
                 unsigned char* vrow = lds + (hz * RZ + hy * RY + hx * VS) * 16;
                 if constexpr (PREC == 0) {
                     *reinterpret_cast<f32x4*>(vrow + q * 16) = v;
+                } else if constexpr (PREC == 5) {
+                    *reinterpret_cast<u32x2*>(vrow + q * 8) = u32x2{bf16_pack(v[0], v[1]), bf16_pack(v[2], v[3])};
                 } else {
                     h4 hi, lo;
 #pragma unroll
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
                         const int hy = rem / HX;
                         const int hx = rem - hy * HX;
                         const bool inb = halo_inb(p, z0 - PAD + hz, y0 - PAD + hy, x0 - PAD + hx);
-                        store_item(hz, hy, hx, halo_finish<PREC != 0>(hs, raw[i], inb, act_mask));
+                        store_item(hz, hy, hx, halo_finish<PREC != 0>(hs, quad_bits_expand(raw[i], hs.b16), inb, act_mask));
                     }
                 }
             } else {
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
         // ------------------------------------------------ taps x k-steps
         // weight ring of 3 taps (prefetch distance 2), statically indexed by the unrolled tap
         const unsigned wchunk = (unsigned)chunk * wchunk_stride;  // scalar byte offset of this chunk
-        constexpr bool LO = PREC != 2;  // PREC 2 streams only the hi halves
+        constexpr bool LO = PREC != 2 && PREC != 5;  // PREC 2 / 5 stream only the hi halves
         u32x4 bq[3][2];
         bq[0][0] = buffer_load16(wrsrc, wlane, wchunk);
         if (LO) bq[0][1] = buffer_load16(wrsrc, wlane, wchunk + wpart);
@@ -248,13 +252,13 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
                         for (int t = 0; t < MT; ++t)
                             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], b[s], acc[t], 0, 0, 0);
                 }
-            } else if constexpr (PREC == 2) {
-                // single product on the f16-rounded operands (the reference's --use_fp16 analogue)
+            } else if constexpr (PREC == 2 || PREC == 5) {
+                // single product on the f16- / bf16-rounded operands
                 const h8 bhi = __builtin_bit_cast(h8, b0);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     const h8 ahi = *reinterpret_cast<const h8*>(lds + arow[t] + tapoff);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[t], 0, 0, 0);
+                    acc[t] = mfma16<PREC == 5>(ahi, bhi, acc[t]);
                 }
             } else {
                 const h8 bhi = __builtin_bit_cast(h8, b0);
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
 // Makefile) so the instantiations build in parallel; the mode-independent parts below
 // (split-K reduction, dispatcher) live in the PREC 0 object only.
 #ifndef DDPM3D_PREC_ONLY
-#error "compile with -DDDPM3D_PREC_ONLY=0, 1 or 2"
+#error "compile with -DDDPM3D_PREC_ONLY=0, 1, 2 or 5"
 #endif
 #if DDPM3D_PREC_ONLY == 0
 
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) 
                 val += ddpm3d_residual(p, n, z, y, x, cout);
             }
             if (p.out_layout == DDPM3D_OUT_NDHWC)
-                p.out[e] = val;
+                ddpm3d_act_store(p.out, e, val, (p.io & DDPM3D_IO_OUT_BF16) != 0);
             else
                 p.out[((size_t)n * p.Cout + cout) * DHW + v] = val;
             s1 += val;
@@ -367,7 +371,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK 
 #pragma unroll
                         for (int c = 0; c < 4; ++c) val[c] += ddpm3d_residual(p, n, z, y, x, q * 4 + c);
                     }
-                    *reinterpret_cast<f32x4*>(p.out + e) = val;
+                    if (p.io & DDPM3D_IO_OUT_BF16)
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + e) =
+                            u32x2{bf16_pack(val[0], val[1]), bf16_pack(val[2], val[3])};
+                    else
+                        *reinterpret_cast<f32x4*>(p.out + e) = val;
                     s1 += val;
                     s2 += val * val;
                 }
@@ -413,6 +421,7 @@ hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st) {
 hipError_t ddpm3d_launch_conv_p0(const ConvK& k, const ConvCfg& c, hipStream_t st);
 hipError_t ddpm3d_launch_conv_p1(const ConvK& k, const ConvCfg& c, hipStream_t st);
 hipError_t ddpm3d_launch_conv_p2(const ConvK& k, const ConvCfg& c, hipStream_t st);
+hipError_t ddpm3d_launch_conv_p5(const ConvK& k, const ConvCfg& c, hipStream_t st);
 hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t st);
 
 hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) {
@@ -421,7 +430,9 @@ hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) 
         case 1: return ddpm3d_launch_conv_p1(k, c, st);
         case 2: return ddpm3d_launch_conv_p2(k, c, st);
         case 3:
-        case 4: return ddpm3d_launch_conv_wz(k, c, st);
+        case 4:
+        case 6: return ddpm3d_launch_conv_wz(k, c, st);
+        case 5: return ddpm3d_launch_conv_p5(k, c, st);
     }
     return hipErrorInvalidValue;
 }
@@ -439,9 +450,11 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     // through LDS) and a 128-row wave tile with one wave per SIMD -- both 3-15 % behind this one
     // once the staging was cut to ~330 instructions per item (conv3d_stage.h).
     if (c.PREC == DDPM3D_PREC_F16_WZ)
-        hipLaunchKernelGGL(conv3d_wz_kernel<false>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+        hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+    else if (c.PREC == DDPM3D_PREC_BF16_WZ)
+        hipLaunchKernelGGL(conv3d_wz_kernel<WZ_BF16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     else
-        hipLaunchKernelGGL(conv3d_wz_kernel<true>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+        hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16X3>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     return hipGetLastError();
 }
 #endif

@@ -6,6 +6,16 @@
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+// one 32x32x16 MFMA on 16-bit operands: f16, or (BF = true) bf16 bit patterns in the same registers
+template <bool BF>
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+    if constexpr (BF)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 // smallest x >= v with x % 16 == res
 constexpr int pad_to_residue(int v, int res) { return v + ((res - v % 16) + 16) % 16; }
@@ -49,17 +59,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
         const size_t Hr = rm == DDPM3D_RES_UP ? p.H / 2 : (rm == DDPM3D_RES_POOL ? (size_t)p.H * 2 : p.H);
         const size_t Wr = rm == DDPM3D_RES_UP ? p.W / 2 : (rm == DDPM3D_RES_POOL ? (size_t)p.W * 2 : p.W);
         const size_t samp_r = (size_t)p.D * Hr * Wr * p.Cout;
+        // bf16 tensors (ddpm3d_conv_desc.io_dtype): 2-byte elements, same offsets in elements
+        const bool o16 = !split && (p.io & DDPM3D_IO_OUT_BF16), r16 = (p.io & DDPM3D_IO_RES_BF16) != 0;
+        const unsigned eso = o16 ? 2u : 4u, esr = r16 ? 2u : 4u;
         if (full && p.out_layout == DDPM3D_OUT_NDHWC && samp_r * 4 < 0xFFFFFFF0ull) {
             const size_t samp = DHW * p.Cout;                       // elements per sample (< 2^30, C ABI guard)
-            const unsigned cstride = (unsigned)p.Cout * 4;          // bytes per voxel
-            float* dst = split ? p.partial + ((size_t)ksplit_idx * p.N + n) * samp : p.out + (size_t)n * samp;
-            const __amdgpu_buffer_rsrc_t drsrc = make_rsrc(dst, (unsigned)(samp * 4));
+            const unsigned cstride = (unsigned)p.Cout * eso;        // bytes per voxel of the output
+            const unsigned rstride = (unsigned)p.Cout * esr;        // ... of the residual
+            float* dst = split ? p.partial + ((size_t)ksplit_idx * p.N + n) * samp
+                               : reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + (size_t)n * samp * eso);
+            const __amdgpu_buffer_rsrc_t drsrc = make_rsrc(dst, (unsigned)(samp * eso));
             const bool resid = rm != DDPM3D_RES_NONE;
             const __amdgpu_buffer_rsrc_t rrsrc =
-                make_rsrc(resid ? p.res + (size_t)n * samp_r : dst, (unsigned)((resid ? samp_r : samp) * 4));
+                resid ? make_rsrc(reinterpret_cast<const char*>(p.res) + (size_t)n * samp_r * esr, (unsigned)(samp_r * esr))
+                      : drsrc;
             // the lane's half adds 4 to the MFMA row: 4 voxels in x (8-wide tile) or one row in y (4-wide)
             const unsigned hx = (4 * half) & (TX - 1), hy = ((4 * half) >> TXL) & (TY - 1);
-            const unsigned vbase = (((unsigned)z0 * p.H + y0 + hy) * p.W + x0 + hx) * cstride + (unsigned)cout * 4;
+            const unsigned vbase = (((unsigned)z0 * p.H + y0 + hy) * p.W + x0 + hx) * cstride + (unsigned)cout * eso;
             const unsigned voff = cvalid ? vbase : DDPM3D_OOB_OFFSET;   // out-of-range lanes: loads 0, stores dropped
             // Residual addressing, also "lane base + wave-uniform offset" (tiles start at even y0, x0):
             //   SAME  x[z][y][x]                      : the output's own offsets
@@ -67,12 +83,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
             //         4 voxels in x are 2 source voxels; in a 4-wide tile its one row in y shares the source row
             //   POOL  mean of x[z][2y+{0,1}][2x+{0,1}]: doubled offsets, four loads
             const unsigned rW = (unsigned)Wr, rH = (unsigned)Hr;
-            unsigned rbase = vbase;
+            unsigned rbase = (((unsigned)z0 * p.H + y0 + hy) * p.W + x0 + hx) * rstride + (unsigned)cout * esr;
             if (rm == DDPM3D_RES_UP)
-                rbase = (((unsigned)z0 * rH + (y0 >> 1)) * rW + (x0 >> 1) + (hx >> 1)) * cstride + (unsigned)cout * 4;
+                rbase = (((unsigned)z0 * rH + (y0 >> 1)) * rW + (x0 >> 1) + (hx >> 1)) * rstride + (unsigned)cout * esr;
             else if (rm == DDPM3D_RES_POOL)
-                rbase = (((unsigned)z0 * rH + 2 * (y0 + hy)) * rW + 2 * (x0 + hx)) * cstride + (unsigned)cout * 4;
-            const unsigned roff = cvalid ? rbase : DDPM3D_OOB_OFFSET;
+                rbase = (((unsigned)z0 * rH + 2 * (y0 + hy)) * rW + 2 * (x0 + hx)) * rstride + (unsigned)cout * esr;
+            unsigned roff_ = 0;
+            // one element of the residual at lane base + scalar offset
+            auto rload = [&](const unsigned so) {
+                if (r16) return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rrsrc, roff_, so, 0) << 16);
+                return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff_, so, 0));
+            };
+            roff_ = cvalid ? rbase : DDPM3D_OOB_OFFSET;
             const float bias = (!split && cvalid) ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
             float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -87,15 +109,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 float r[16];
                 if (rm == DDPM3D_RES_SAME) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg)
-                        r[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, soff[reg], 0));
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
+                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
+                        r[reg] = rload((unsigned)((tz * p.H + ty) * p.W + tx) * rstride);
+                    }
                 } else if (rm == DDPM3D_RES_UP) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
                         const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
-                        const unsigned so = (unsigned)((tz * rH + (ty >> 1)) * rW + (tx >> 1)) * cstride;
-                        r[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, so, 0));
+                        r[reg] = rload((unsigned)((tz * rH + (ty >> 1)) * rW + (tx >> 1)) * rstride);
                     }
                 } else if (rm == DDPM3D_RES_POOL) {
                     // AvgPool3d window order (h, w): ((r00 + r01) + r10) + r11, then * 1/4 (ddpm3d_residual)
@@ -103,11 +127,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                     for (int reg = 0; reg < 16; ++reg) {
                         const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
                         const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
-                        const unsigned so = (unsigned)((tz * rH + 2 * ty) * rW + 2 * tx) * cstride;
-                        const float r00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, so, 0));
-                        const float r01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, so + cstride, 0));
-                        const float r10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, so + rW * cstride, 0));
-                        const float r11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff, so + (rW + 1) * cstride, 0));
+                        const unsigned so = (unsigned)((tz * rH + 2 * ty) * rW + 2 * tx) * rstride;
+                        const float r00 = rload(so), r01 = rload(so + rstride);
+                        const float r10 = rload(so + rW * rstride), r11 = rload(so + (rW + 1) * rstride);
                         r[reg] = (((r00 + r01) + r10) + r11) * 0.25f;
                     }
                 }
@@ -120,7 +142,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                         s1 += val;
                         s2 = fmaf(val, val, s2);
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), drsrc, voff, soff[reg], 0);
+                    if (o16)
+                        __builtin_amdgcn_raw_buffer_store_b16(ddpm3d_to_bf16(val), drsrc, voff, soff[reg], 0);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), drsrc, voff, soff[reg], 0);
                 }
             }
             if (!split && p.stats != nullptr) {
@@ -170,7 +195,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 const size_t vox = ((size_t)z * p.H + y) * p.W + x;
                 if (p.res_mode != DDPM3D_RES_NONE) val += ddpm3d_residual(p, n, z, y, x, cout);
                 if (p.out_layout == DDPM3D_OUT_NDHWC)
-                    p.out[((size_t)n * DHW + vox) * p.Cout + cout] = val;
+                    ddpm3d_act_store(p.out, ((size_t)n * DHW + vox) * p.Cout + cout, val, (p.io & DDPM3D_IO_OUT_BF16) != 0);
                 else
                     p.out[((size_t)n * p.Cout + cout) * DHW + vox] = val;
                 s1 += val;

@@ -31,8 +31,33 @@ __device__ __forceinline__ f32x4 affine_act(f32x4 v, f32x4 a, f32x4 b) {
     return r;
 }
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// four bf16 (two dwords) -> four fp32
+__device__ __forceinline__ f32x4 bf16x4_expand(u32x2 v) {
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, v[0] << 16);
+    r[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
+    r[2] = __builtin_bit_cast(float, v[1] << 16);
+    r[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
+    return r;
+}
+// two fp32 -> packed bf16 pair (round to nearest even, NaN stays NaN)
+__device__ __forceinline__ unsigned bf16_pack(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// quad q4 (4 channels starting at element offset e) of an fp32 or bf16 activation tensor
+__device__ __forceinline__ f32x4 act_quad(const float* base, size_t e, bool bf16) {
+    if (bf16) return bf16x4_expand(*reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + e));
+    return *reinterpret_cast<const f32x4*>(base + e);
+}
+
 struct HaloSrc {
     const float* src;  // source tensor of this chunk (after the concat split)
+    bool b16;          // it holds bf16 elements (ddpm3d_conv_desc.io_dtype)
     unsigned src_bytes;  // its extent (buffer descriptor num_records)
     int Cs;            // its channel count
     int cb;            // first channel of the chunk inside it
@@ -47,6 +72,7 @@ __device__ __forceinline__ HaloSrc halo_src(const ConvK& p, int n, int chunk, in
     const int c0 = chunk * CK;
     const bool from0 = c0 < p.C0;
     h.src = from0 ? p.src0 : p.src1;
+    h.b16 = (p.io & (from0 ? DDPM3D_IO_SRC0_BF16 : DDPM3D_IO_SRC1_BF16)) != 0;
     h.src_bytes = from0 ? p.src0_bytes : p.src1_bytes;
     h.Cs = from0 ? p.C0 : p.C1;
     h.cb = from0 ? c0 : c0 - p.C0;
@@ -70,20 +96,20 @@ __device__ __forceinline__ f32x4 halo_fetch(const ConvK& p, const HaloSrc& h, in
     if (!inb) return v;
     if (p.in_mode == DDPM3D_IN_SAME) {
         const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
-        v = *reinterpret_cast<const f32x4*>(h.src + vox * h.Cs + h.cb + q * 4);
+        v = act_quad(h.src, vox * h.Cs + h.cb + q * 4, h.b16);
         if (h.has_aff) v = p.act ? affine_act<1, FAST>(v, h.ga, h.gb) : affine_act<0, FAST>(v, h.ga, h.gb);
     } else if (p.in_mode == DDPM3D_IN_UP) {
         const size_t vox = (((size_t)n * p.D + z) * h.Hs + (y >> 1)) * h.Ws + (x >> 1);
-        v = *reinterpret_cast<const f32x4*>(h.src + vox * h.Cs + h.cb + q * 4);
+        v = act_quad(h.src, vox * h.Cs + h.cb + q * 4, h.b16);
         if (h.has_aff) v = p.act ? affine_act<1, FAST>(v, h.ga, h.gb) : affine_act<0, FAST>(v, h.ga, h.gb);
     } else if (p.in_mode == DDPM3D_IN_POOL) {
         // AvgPool3d window order (h, w): ((s00 + s01) + s10) + s11, then * 1/4
         const size_t vox = (((size_t)n * p.D + z) * h.Hs + 2 * y) * h.Ws + 2 * x;
-        const float* b0 = h.src + vox * h.Cs + h.cb + q * 4;
-        f32x4 s00 = *reinterpret_cast<const f32x4*>(b0);
-        f32x4 s01 = *reinterpret_cast<const f32x4*>(b0 + h.Cs);
-        f32x4 s10 = *reinterpret_cast<const f32x4*>(b0 + (size_t)h.Ws * h.Cs);
-        f32x4 s11 = *reinterpret_cast<const f32x4*>(b0 + (size_t)h.Ws * h.Cs + h.Cs);
+        const size_t e0 = vox * h.Cs + h.cb + q * 4;
+        f32x4 s00 = act_quad(h.src, e0, h.b16);
+        f32x4 s01 = act_quad(h.src, e0 + h.Cs, h.b16);
+        f32x4 s10 = act_quad(h.src, e0 + (size_t)h.Ws * h.Cs, h.b16);
+        f32x4 s11 = act_quad(h.src, e0 + (size_t)h.Ws * h.Cs + h.Cs, h.b16);
         if (h.has_aff) {
             if (p.act) {
                 s00 = affine_act<1, FAST>(s00, h.ga, h.gb); s01 = affine_act<1, FAST>(s01, h.ga, h.gb);
@@ -116,7 +142,6 @@ __device__ __forceinline__ bool halo_inb(const ConvK& p, int z, int y, int x) {
 // loop (54 pairs for the weights alone), spills them and then waits vmcnt(0) behind every
 // reload.  A uniform descriptor leaves nothing per-tap to hoist, and an offset beyond
 // num_records reads as 0, which is exactly the conv's zero padding (no branch).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define DDPM3D_OOB_OFFSET 0xFFFFFFF0u
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -124,6 +149,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 __device__ __forceinline__ u32x4 buffer_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+__device__ __forceinline__ u32x2 buffer_load8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+}
+// one channel quad of an fp32 (16 B) or bf16 (8 B) tensor as raw bits; quad_bits_expand() when consumed
+__device__ __forceinline__ u32x4 buffer_load_quad(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, bool b16) {
+    if (b16) {
+        const u32x2 t = buffer_load8(r, voff, soff);
+        return u32x4{t[0], t[1], 0u, 0u};
+    }
+    return buffer_load16(r, voff, soff);
+}
+__device__ __forceinline__ f32x4 quad_bits_expand(u32x4 bits, bool b16) {
+    return b16 ? bf16x4_expand(u32x2{bits[0], bits[1]}) : __builtin_bit_cast(f32x4, bits);
 }
 
 // Voxel index (in the SOURCE tensor's D x Hs x Ws grid) of a halo item, or -1 outside the

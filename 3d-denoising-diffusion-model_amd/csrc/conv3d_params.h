@@ -37,6 +37,7 @@ struct ConvK {
     int wstat;  // weight-stationary workgroup -> XCD order (conv3d_load.h wg_id)
     int reduce_vox;  // voxels per statistics row of the split-K reduce
     int hint;        // ddpm3d_conv_desc.kernel_hint
+    int io;          // ddpm3d_conv_desc.io_dtype (DDPM3D_IO_* bits)
 };
 
 struct ConvCfg {
@@ -129,7 +130,8 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
 // f16 [tap][ci/16][hi|lo][CoutPad][16] followed by CoutPad fp32 output scales for PREC 1
 static inline size_t ddpm3d_packed_bytes(int Cout, int Cin, int ksize, int prec) {
     // Winograd-D form: 4 transformed depth taps x 3 x 3 = 36 instead of 27
-    const size_t taps = (prec == DDPM3D_PREC_F16X3_WZ || prec == DDPM3D_PREC_F16_WZ) ? 36 : (size_t)ksize * ksize * ksize;
+    const size_t taps = (prec == DDPM3D_PREC_F16X3_WZ || prec == DDPM3D_PREC_F16_WZ || prec == DDPM3D_PREC_BF16_WZ)
+                            ? 36 : (size_t)ksize * ksize * ksize;
     const size_t body = taps * ddpm3d_cin_pad(Cin) * ddpm3d_cout_pad(Cout) * 4;
     return prec != 0 ? body + (size_t)ddpm3d_cout_pad(Cout) * 4 : body;  // modes 1 and 2 share the image
 }
@@ -139,22 +141,39 @@ hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st);
 
 // Residual term of the conv epilogue for output element (n, z, y, x, cout);
 // shared by the conv kernel and the split-K reduce kernel.
+// element e of an activation tensor that holds fp32 or (bf16 = true) bf16 values
+__device__ __forceinline__ float ddpm3d_act_load(const float* base, size_t e, bool bf16) {
+    if (bf16) return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(base)[e] << 16);
+    return base[e];
+}
+// fp32 -> bf16, round to nearest even, NaN stays NaN (hipcc lowers the cast to v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned short ddpm3d_to_bf16(float v) {
+    return __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+__device__ __forceinline__ void ddpm3d_act_store(float* base, size_t e, float v, bool bf16) {
+    if (bf16) reinterpret_cast<unsigned short*>(base)[e] = ddpm3d_to_bf16(v);
+    else base[e] = v;
+}
+
 __device__ __forceinline__ float ddpm3d_residual(const ConvK& p, int n, int z, int y, int x, int cout) {
+    const bool b16 = (p.io & DDPM3D_IO_RES_BF16) != 0;
     if (p.res_mode == DDPM3D_RES_SAME) {
         const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
-        return p.res[vox * p.Cout + cout];
+        return ddpm3d_act_load(p.res, vox * p.Cout + cout, b16);
     }
     if (p.res_mode == DDPM3D_RES_UP) {
         const int Hr = p.H / 2, Wr = p.W / 2;
         const size_t rv = (((size_t)n * p.D + z) * Hr + (y >> 1)) * Wr + (x >> 1);
-        return p.res[rv * p.Cout + cout];
+        return ddpm3d_act_load(p.res, rv * p.Cout + cout, b16);
     }
     if (p.res_mode == DDPM3D_RES_POOL) {
         // AvgPool3d window order (h, w): ((r00 + r01) + r10) + r11, then * 1/4
         const int Hr = p.H * 2, Wr = p.W * 2;
         const size_t rv = (((size_t)n * p.D + z) * Hr + 2 * y) * Wr + 2 * x;
-        const float* r0 = p.res + rv * p.Cout + cout;
-        const float r = ((r0[0] + r0[p.Cout]) + r0[(size_t)Wr * p.Cout]) + r0[(size_t)Wr * p.Cout + p.Cout];
+        const size_t e = rv * p.Cout + cout;
+        const float r = ((ddpm3d_act_load(p.res, e, b16) + ddpm3d_act_load(p.res, e + p.Cout, b16)) +
+                         ddpm3d_act_load(p.res, e + (size_t)Wr * p.Cout, b16)) +
+                        ddpm3d_act_load(p.res, e + (size_t)Wr * p.Cout + p.Cout, b16);
         return r * 0.25f;
     }
     return 0.0f;

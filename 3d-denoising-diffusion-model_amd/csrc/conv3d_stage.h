@@ -22,7 +22,8 @@
 #pragma once
 #include "conv3d_epilogue.h"
 
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// arithmetic of the staged operands: hi + lo f16 (three MFMAs per product), hi f16 only, bf16
+enum { WZ_F16X3 = 0, WZ_F16 = 1, WZ_BF16 = 2 };
 
 // two fp32 -> packed f16 hi (RNE) and packed f16 lo = f16(s - hi); the subtraction is exact
 __device__ __forceinline__ void split_pair(float s0, float s1, unsigned& hi, unsigned& lo) {
@@ -49,6 +50,7 @@ struct WzGeom {
 // Per-thread, launch-invariant part of the staging (256 staging threads, thread = lt).
 struct StageLane {
     unsigned vo0[WzGeom::NL], vo1[WzGeom::NL];   // byte offset of slot i's voxel at plane zb in src0 / src1
+    unsigned es0, es1;                           // bytes per element of src0 / src1 (4, or 2 = bf16)
     int lds[WzGeom::NL];                         // byte offset of slot i inside a plane of the image
     bool ok[WzGeom::NL];                         // slot exists and its (y, x) lies inside the volume
     unsigned plane0, plane1;                     // bytes per z-plane of src0 / src1
@@ -66,8 +68,10 @@ __device__ __forceinline__ StageLane stage_lane(const ConvK& p, int lt, int n, i
     const int Hs = p.H >> up, Ws = p.W >> up;
     s.q = lt & 3;
     s.zb = zb;
-    s.plane0 = (unsigned)(Hs * Ws) * (unsigned)p.C0 * 4u;
-    s.plane1 = (unsigned)(Hs * Ws) * (unsigned)p.C1 * 4u;
+    s.es0 = (p.io & DDPM3D_IO_SRC0_BF16) ? 2u : 4u;
+    s.es1 = (p.io & DDPM3D_IO_SRC1_BF16) ? 2u : 4u;
+    s.plane0 = (unsigned)(Hs * Ws) * (unsigned)p.C0 * s.es0;
+    s.plane1 = (unsigned)(Hs * Ws) * (unsigned)p.C1 * s.es1;
     // act: e = exp2(-y log2e) with yS = S y;  none: e = exp2(-126) ~ 1e-38, 1 + e == 1, yS * 1 = yS
     s.km = p.act ? -1.44269504088896341f / scale : 0.0f;
     s.ka = p.act ? 0.0f : -126.0f;
@@ -79,8 +83,8 @@ __device__ __forceinline__ StageLane stage_lane(const ConvK& p, int lt, int n, i
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         s.ok[i] = idx < WzGeom::HC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         const unsigned vox = (unsigned)(((n * p.D + zb) * Hs + (y >> up)) * Ws + (x >> up));
-        s.vo0[i] = s.ok[i] ? vox * (unsigned)p.C0 * 4u + s.q * 16u : DDPM3D_OOB_OFFSET;
-        s.vo1[i] = s.ok[i] ? vox * (unsigned)p.C1 * 4u + s.q * 16u : DDPM3D_OOB_OFFSET;
+        s.vo0[i] = s.ok[i] ? (vox * (unsigned)p.C0 + s.q * 4u) * s.es0 : DDPM3D_OOB_OFFSET;
+        s.vo1[i] = s.ok[i] ? (vox * (unsigned)p.C1 + s.q * 4u) * s.es1 : DDPM3D_OOB_OFFSET;
         s.lds[i] = (hy * WzGeom::RY + hx * WzGeom::VS) * 16 + s.q * 8;
     }
     return s;
@@ -106,9 +110,10 @@ __device__ __forceinline__ void stage_zero_border(const StageLane& s, unsigned c
 // consecutive z-pairs share their inner planes) + the chunk's affine.
 template <int NPL>
 struct StageRawT {
-    f32x4 v[WzGeom::NL][NPL];
+    u32x4 v[WzGeom::NL][NPL];   // raw bits: four fp32, or four bf16 in the low half
     f32x4 ga, gb;
     unsigned zmask;   // bit k: plane z0 - 1 + k lies inside the volume (uniform)
+    bool b16;         // this item's source holds bf16 (uniform)
 };
 typedef StageRawT<4> StageRaw;
 
@@ -119,7 +124,8 @@ __device__ __forceinline__ void stage_issue(const ConvK& p, const StageLane& s, 
     const bool from0 = c0 < p.C0;
     const __amdgpu_buffer_rsrc_t rs = from0 ? make_rsrc(p.src0, p.src0_bytes) : make_rsrc(p.src1, p.src1_bytes);
     const unsigned plane = from0 ? s.plane0 : s.plane1;
-    const unsigned cb4 = (unsigned)(from0 ? c0 : c0 - p.C0) * 4u;
+    const unsigned cb4 = (unsigned)(from0 ? c0 : c0 - p.C0) * (from0 ? s.es0 : s.es1);
+    r.b16 = (from0 ? s.es0 : s.es1) == 2u;
     r.zmask = 0;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -129,7 +135,7 @@ __device__ __forceinline__ void stage_issue(const ConvK& p, const StageLane& s, 
             const unsigned soff = cb4 + (unsigned)(z - s.zb) * plane;
 #pragma unroll
             for (int i = 0; i < WzGeom::NL; ++i)
-                r.v[i][k] = __builtin_bit_cast(f32x4, buffer_load16(rs, from0 ? s.vo0[i] : s.vo1[i], soff));
+                r.v[i][k] = buffer_load_quad(rs, from0 ? s.vo0[i] : s.vo1[i], soff, r.b16);
         }
     }
     if (p.affA != nullptr) {
@@ -141,9 +147,9 @@ __device__ __forceinline__ void stage_issue(const ConvK& p, const StageLane& s, 
     }
 }
 
-// raw -> image(s) at `buf` (z-pair zp at buf + zp * WzGeom::BUF).  X3 = false keeps only the hi
-// halves (f16 mode).
-template <bool X3, int NPL = 4>
+// raw -> image(s) at `buf` (z-pair zp at buf + zp * WzGeom::BUF).  MODE WZ_F16 keeps only the hi
+// halves; WZ_BF16 stores bf16 pairs in the hi slots (s.scale is 1 then).
+template <int MODE, int NPL = 4>
 __device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<NPL>& r, unsigned char* buf) {
     constexpr int NZP = (NPL - 2) / 2;
     float sa[4], sb[4];
@@ -158,9 +164,10 @@ __device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             if (r.zmask & (1u << k)) {
+                const f32x4 x = quad_bits_expand(r.v[i][k], r.b16);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float ys = __builtin_fmaf(r.v[i][k][c], sa[c], sb[c]);
+                    const float ys = __builtin_fmaf(x[c], sa[c], sb[c]);
                     const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(ys, s.km, s.ka));
                     d[k][c] = ys * __builtin_amdgcn_rcpf(1.0f + e);
                 }
@@ -182,12 +189,16 @@ __device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<
                              : j == 1 ? d[b + 1][c] + d[b + 2][c]
                              : j == 2 ? d[b + 2][c] - d[b + 1][c]
                                       : d[b + 1][c] - d[b + 3][c];
-                    unsigned h0, h1, l0, l1;
-                    split_pair(v[0], v[1], h0, l0);
-                    split_pair(v[2], v[3], h1, l1);
                     unsigned char* vrow = buf + zp * WzGeom::BUF + j * WzGeom::RZ * 16 + s.lds[i];
-                    *reinterpret_cast<u32x2*>(vrow) = u32x2{h0, h1};
-                    if (X3) *reinterpret_cast<u32x2*>(vrow + 32) = u32x2{l0, l1};
+                    if constexpr (MODE == WZ_BF16) {
+                        *reinterpret_cast<u32x2*>(vrow) = u32x2{bf16_pack(v[0], v[1]), bf16_pack(v[2], v[3])};
+                    } else {
+                        unsigned h0, h1, l0, l1;
+                        split_pair(v[0], v[1], h0, l0);
+                        split_pair(v[2], v[3], h1, l1);
+                        *reinterpret_cast<u32x2*>(vrow) = u32x2{h0, h1};
+                        if (MODE == WZ_F16X3) *reinterpret_cast<u32x2*>(vrow + 32) = u32x2{l0, l1};
+                    }
                 }
         }
     }

@@ -27,10 +27,12 @@
 #pragma once
 #include "conv3d_stage.h"
 
-// X3: three f16 MFMAs per product on hi/lo-split operands (DDPM3D_PREC_F16X3_WZ); false: one MFMA
-// on the hi halves of the same packed image and LDS layout (DDPM3D_PREC_F16_WZ)
-template <bool X3>
+// MODE WZ_F16X3: three f16 MFMAs per product on hi/lo-split operands (DDPM3D_PREC_F16X3_WZ);
+// WZ_F16: one MFMA on the hi halves of the same packed image and LDS layout (DDPM3D_PREC_F16_WZ);
+// WZ_BF16: one bf16 MFMA on bf16-rounded operands, no scaling (DDPM3D_PREC_BF16_WZ)
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
+    constexpr bool X3 = MODE == WZ_F16X3;
     constexpr int CK = DDPM3D_CONV_CK, NT = 36;
     constexpr int TX = 8, TXL = 3, TYL = 3;
     constexpr int VS = WzGeom::VS, RY = WzGeom::RY, RZ = WzGeom::RZ;
@@ -77,7 +79,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     const int chunk_begin = wg.split * p.chunks_per_split;
     const int chunk_end = min(nchunks, chunk_begin + p.chunks_per_split);
 
-    const ActScale asc = act_scale(p, n, 2.0f);   // the input transform adds two planes
+    ActScale asc = {1.0f, 1.0f};
+    if constexpr (MODE != WZ_BF16) asc = act_scale(p, n, 2.0f);   // the input transform adds two planes
     const StageLane sl = stage_lane(p, tid, n, y0, x0, max(z0 - 1, 0), asc.s);
     stage_zero_border(sl, lds, 1, tid);
     StageRaw raw;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         const bool more = chunk + 1 < chunk_end;
         const unsigned char* bufc = lds;
         __syncthreads();
-        stage_write<X3>(sl, raw, lds);
+        stage_write<MODE>(sl, raw, lds);
         __syncthreads();
 
         // ---- 36 taps (j, dy, dx); weight ring of 3 taps, prefetch distance 2; the stream's byte
@@ -140,14 +143,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
                 const h8 blo = __builtin_bit_cast(h8, bq[tap % 3][L]);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap & 1][t][L], bhi, acc[j][t], 0, 0, 0);
+                    acc[j][t] = mfma16<false>(af[tap & 1][t][L], bhi, acc[j][t]);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap & 1][t][0], blo, acc[j][t], 0, 0, 0);
+                    acc[j][t] = mfma16<false>(af[tap & 1][t][0], blo, acc[j][t]);
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[tap & 1][t][0], bhi, acc[j][t], 0, 0, 0);
+                acc[j][t] = mfma16<MODE == WZ_BF16>(af[tap & 1][t][0], bhi, acc[j][t]);
         }
     }
 

@@ -50,8 +50,17 @@ __global__ __launch_bounds__(256) void pack_x3_scale_kernel(const float* __restr
 
 // Pass 2: OIDHW -> [tap][ci/16][hi|lo][CoutPad][16 f16] of w * s[cout] (zero padded),
 // with s = 1 / wscale[cout] recovered exactly from pass 1's output.
+// bf16 = true: the bf16 mode's image in the same layout -- hi = bf16(w) (no scale, wscale = 1), lo = 0
+__device__ __forceinline__ _Float16 bf16_bits_as_h(float v) {
+    return __builtin_bit_cast(_Float16, __builtin_bit_cast(unsigned short, (__bf16)v));
+}
+__global__ void pack_ones_kernel(float* __restrict__ wscale, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) wscale[i] = 1.0f;
+}
+
 __global__ void pack_x3_kernel(const float* __restrict__ w, const float* __restrict__ wscale, int Cout,
-                               int Cin, int taps, int CoutPad, int CinPad, _Float16* __restrict__ out) {
+                               int Cin, int taps, int CoutPad, int CinPad, _Float16* __restrict__ out, bool bf16) {
     const size_t total = (size_t)taps * CinPad * CoutPad;  // one (hi, lo) pair per element
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -64,8 +73,8 @@ __global__ void pack_x3_kernel(const float* __restrict__ w, const float* __restr
         float v = 0.0f;
         if (co < Cout && ci < Cin)
             v = w[((size_t)co * Cin + ci) * taps + tap] * (1.0f / wscale[co]);
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
+        const _Float16 hi = bf16 ? bf16_bits_as_h(v) : (_Float16)v;
+        const _Float16 lo = bf16 ? (_Float16)0.0f : (_Float16)(v - (float)hi);
         const size_t base = (((size_t)tap * (CinPad / 16) + cb) * 2) * CoutPad * 16;
         out[base + (size_t)co * 16 + j] = hi;
         out[base + (size_t)CoutPad * 16 + (size_t)co * 16 + j] = lo;
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256) void pack_wz_scale_kernel(const float* __restr
 }
 
 __global__ void pack_wz_kernel(const float* __restrict__ w, const float* __restrict__ wscale, int Cout, int Cin,
-                               int CoutPad, int CinPad, _Float16* __restrict__ out) {
+                               int CoutPad, int CinPad, _Float16* __restrict__ out, bool bf16) {
     const size_t total = (size_t)36 * CinPad * CoutPad;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -119,8 +128,8 @@ __global__ void pack_wz_kernel(const float* __restrict__ w, const float* __restr
         float v = 0.0f;
         if (co < Cout && ci < Cin)
             v = wz_weight(w, (size_t)co * Cin + ci, tap / 9, tap % 9) * (1.0f / wscale[co]);
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
+        const _Float16 hi = bf16 ? bf16_bits_as_h(v) : (_Float16)v;
+        const _Float16 lo = bf16 ? (_Float16)0.0f : (_Float16)(v - (float)hi);
         const size_t base = (((size_t)tap * (CinPad / 16) + cb) * 2) * CoutPad * 16;
         out[base + (size_t)co * 16 + jj] = hi;
         out[base + (size_t)CoutPad * 16 + (size_t)co * 16 + jj] = lo;
@@ -129,16 +138,21 @@ __global__ void pack_wz_kernel(const float* __restrict__ w, const float* __restr
 
 hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, int prec, void* out, hipStream_t st) {
     const int CoutPad = ddpm3d_cout_pad(Cout), CinPad = ddpm3d_cin_pad(Cin);
-    if (prec == DDPM3D_PREC_F16X3_WZ || prec == DDPM3D_PREC_F16_WZ) {   // [f16 image of 36 transformed taps][CoutPad fp32 wscale]
+    const bool bf16 = prec == DDPM3D_PREC_BF16 || prec == DDPM3D_PREC_BF16_WZ;
+    if (prec == DDPM3D_PREC_F16X3_WZ || prec == DDPM3D_PREC_F16_WZ || prec == DDPM3D_PREC_BF16_WZ) {
+        // [16-bit image of 36 transformed taps][CoutPad fp32 wscale]
         const size_t total = (size_t)36 * CinPad * CoutPad;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         float* wscale = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + total * 4);
-        hipLaunchKernelGGL(pack_wz_scale_kernel, dim3(CoutPad), dim3(256), 0, st, w, Cout, Cin, wscale);
+        if (bf16)
+            hipLaunchKernelGGL(pack_ones_kernel, dim3((CoutPad + 255) / 256), dim3(256), 0, st, wscale, CoutPad);
+        else
+            hipLaunchKernelGGL(pack_wz_scale_kernel, dim3(CoutPad), dim3(256), 0, st, w, Cout, Cin, wscale);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(pack_wz_kernel, dim3(blocks), dim3(256), 0, st, w, wscale, Cout, Cin, CoutPad, CinPad,
-                           (_Float16*)out);
+                           (_Float16*)out, bf16);
         return hipGetLastError();
     }
     const int taps = ks * ks * ks;
@@ -152,11 +166,14 @@ hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, int pre
     }
     // PREC 1: [f16 image (total hi/lo pairs = total*4 bytes)][CoutPad fp32 wscale]
     float* wscale = reinterpret_cast<float*>(reinterpret_cast<char*>(out) + total * 4);
-    hipLaunchKernelGGL(pack_x3_scale_kernel, dim3(CoutPad), dim3(256), 0, st, w, Cout, Cin * taps, wscale);
+    if (bf16)
+        hipLaunchKernelGGL(pack_ones_kernel, dim3((CoutPad + 255) / 256), dim3(256), 0, st, wscale, CoutPad);
+    else
+        hipLaunchKernelGGL(pack_x3_scale_kernel, dim3(CoutPad), dim3(256), 0, st, w, Cout, Cin * taps, wscale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(pack_x3_kernel, dim3(blocks), dim3(256), 0, st, w, wscale, Cout, Cin, taps, CoutPad,
-                       CinPad, (_Float16*)out);
+                       CinPad, (_Float16*)out, bf16);
     return hipGetLastError();
 }
 

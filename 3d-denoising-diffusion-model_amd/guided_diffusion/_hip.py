@@ -21,10 +21,12 @@ ACT_NONE, ACT_SILU = 0, 1
 OUT_NDHWC, OUT_NCDHW = 0, 1
 F_LEARN_SIGMA, F_PREDICT_XSTART, F_CLIP = 1, 2, 4
 NCOEF = 8
-PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X3_WZ, PREC_F16_WZ = 0, 1, 2, 3, 4
-PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16}
+PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X3_WZ, PREC_F16_WZ, PREC_BF16, PREC_BF16_WZ = 0, 1, 2, 3, 4, 5, 6
+PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16, "bf16": PREC_BF16}
 # the Winograd-along-depth form of a mode (same arithmetic, 2/3 of the MFMAs), where one exists
-WINOGRAD_OF = {PREC_F16X3: PREC_F16X3_WZ, PREC_F16: PREC_F16_WZ}
+WINOGRAD_OF = {PREC_F16X3: PREC_F16X3_WZ, PREC_F16: PREC_F16_WZ, PREC_BF16: PREC_BF16_WZ}
+# ddpm3d_conv_desc.io_dtype bits: which activation tensors hold bf16
+IO_SRC0_BF16, IO_SRC1_BF16, IO_OUT_BF16, IO_RES_BF16 = 1, 2, 4, 8
 ABI_VERSION = 8
 # ddpm3d_conv_desc.kernel_hint bits (launch orders of identical arithmetic; tests and A/B measurements)
 HINT_WSTAT_OFF, HINT_WSTAT_ON = 0x100, 0x200
@@ -43,7 +45,7 @@ class ConvDesc(C.Structure):
         ("res", _fp), ("out", _fp), ("out_layout", C.c_int32), ("stats_rows", C.c_int32),
         ("stats", _fp), ("workspace", _fp), ("workspace_bytes", C.c_size_t),
         ("kernel_hint", C.c_int32), ("in_bound_count", C.c_int32), ("in_bound", _fp),
-        ("in_bound_stride", C.c_int32), ("reserved0", C.c_int32),
+        ("in_bound_stride", C.c_int32), ("io_dtype", C.c_int32),
     ]
 
 

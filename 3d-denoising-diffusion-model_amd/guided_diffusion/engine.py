@@ -29,11 +29,16 @@ from . import _hip as H
 
 
 class Act:
-    """An NDHWC activation produced by a conv epilogue, with its GN partial sums."""
+    """An NDHWC activation produced by a conv epilogue (fp32, or bf16 in the bf16 mode), with its
+    GN partial sums."""
     __slots__ = ("buf", "C", "D", "H", "W", "stats", "rows")
 
     def __init__(self, buf, Cn, D, Hh, W, stats, rows):
         self.buf, self.C, self.D, self.H, self.W, self.stats, self.rows = buf, Cn, D, Hh, W, stats, rows
+
+    @property
+    def bf16(self):
+        return self.buf.dtype == torch.bfloat16
 
     @property
     def voxels(self):
@@ -63,7 +68,8 @@ class UNetEngine:
     def __init__(self, topo, params, model_channels, film, device, precision="f32"):
         """precision: "f32" = exact fp32 MFMA everywhere; "f16x3" = every conv evaluates
         each fp32 product as three f16 MFMAs (fp32-equivalent accuracy, see
-        include/ddpm3d.h)."""
+        include/ddpm3d.h); "f16" = one f16 MFMA per product (the reference's --use_fp16);
+        "bf16" = one bf16 MFMA per product AND the residual stream stored in bf16."""
         if precision not in H.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(H.PRECISIONS))
         self.precision = precision
@@ -181,21 +187,26 @@ class _Plan:
         self.pool = {}
         self.act_bytes = 0
 
-        def new_act(Cn, d, h, w):
+        # bf16 mode: the residual stream (every tensor a conv writes and convs read) is stored in
+        # bf16; tensors read by the fp32-only kernels (attention, subsample, gn_stats) stay fp32
+        self.bf16 = eng.precision == "bf16"
+
+        def new_act(Cn, d, h, w, fp32=False):
             # the statistics buffer is attached by the conv step that produces the tensor
             # (its row count depends on how that conv is tiled / split)
             numel = N * d * h * w * Cn
-            free = self.pool.get(numel)
+            dt = torch.bfloat16 if (self.bf16 and not fp32) else torch.float32
+            free = self.pool.get((numel, dt))
             if free:
                 buf = free.pop()
             else:
-                buf = torch.empty(numel, dtype=torch.float32, device=dev)
-                self.act_bytes += 4 * numel
+                buf = torch.empty(numel, dtype=dt, device=dev)
+                self.act_bytes += buf.element_size() * numel
                 self.keep.append(buf)  # descriptors hold raw pointers: the plan owns every buffer
             return Act(buf, Cn, d, h, w, None, 0)
 
         def release(act):
-            self.pool.setdefault(act.buf.numel(), []).append(act.buf)
+            self.pool.setdefault((act.buf.numel(), act.buf.dtype), []).append(act.buf)
 
         self.ws_descs = []      # conv descriptors that need the shared split-K workspace
         self.ws_bytes = 0
@@ -310,6 +321,13 @@ class _Plan:
         if aff is not None:
             d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
         d.act = act
+        io = 0
+        if not planar:
+            io |= H.IO_SRC0_BF16 if srcs[0].bf16 else 0
+            io |= H.IO_SRC1_BF16 if (len(srcs) > 1 and srcs[1].bf16) else 0
+        io |= H.IO_OUT_BF16 if (out is not None and out.bf16) else 0
+        io |= H.IO_RES_BF16 if (res is not None and res.bf16) else 0
+        d.io_dtype = io
         if bound is None:
             raise RuntimeError("conv_step without an input bound")
         d.in_bound = bound[0].data_ptr() + 4 * bound[1]
@@ -365,10 +383,10 @@ class _Plan:
                 raise RuntimeError("Downsample needs even H, W (got %dx%d)" % (x.H, x.W))
             pc = eng.conv[e.prefix + ".op"]
             lib, N = eng.lib, self.N
-            full = self.new_act(pc.Cout, x.D, x.H, x.W)
+            full = self.new_act(pc.Cout, x.D, x.H, x.W, fp32=True)      # read by ddpm3d_subsample_hw2
             _, _, bnd = self.finalize([x], None, None)
             self.conv_step(pc, [x], full, want_stats=False, bound=(bnd, 1, 32, 2))
-            y = self.new_act(pc.Cout, x.D, x.H // 2, x.W // 2)
+            y = self.new_act(pc.Cout, x.D, x.H // 2, x.W // 2, fp32=True)   # read by ddpm3d_gn_stats
             self.steps.append((lib.ddpm3d_subsample_hw2,
                                [H.ptr(full.buf), N, x.D, x.H, x.W, pc.Cout, H.ptr(y.buf), 0]))
             y.rows = lib.ddpm3d_gn_stats_rows(y.voxels)
@@ -393,18 +411,18 @@ class _Plan:
         if ch not in (32, 64, 128):
             raise NotImplementedError("attention with %d channels per head (32, 64 or 128 are built)" % ch)
         A, B, bnd = self.finalize([x], p + ".norm", None)
-        qkv = self.new_act(3 * Cn, x.D, x.H, x.W)
+        qkv = self.new_act(3 * Cn, x.D, x.H, x.W, fp32=True)           # read by the attention kernel
         self.conv_step(eng.conv[p + ".qkv"], [x], qkv, aff=(A, B), act=H.ACT_NONE, bound=(bnd, 0, 32, 2))
         # range of q, k, v (and of the attention output, a convex combination of v) from qkv's
         # own partial sums
         _, _, qb = self.finalize([qkv], None, None)
-        a = self.new_act(Cn, x.D, x.H, x.W)
+        a = self.new_act(Cn, x.D, x.H, x.W, fp32=True)
         # two T x T x ch products per head (the reference's count_flops_attn, unet.py:308-325)
         self.conv_meta[len(self.steps)] = ("attention_ch%d" % ch, 4.0 * N * heads * float(x.voxels) ** 2 * ch)
         # the two products in the model's arithmetic: exact fp32 MFMA in the "f32" mode, fp32-grade
         # f16x3 otherwise (in the "f16" mode too: the reference's fp16 torso keeps the softmax in
         # fp32 (unet.py:351), and f16-rounded scores would cost more accuracy than the convs do)
-        aprec = H.PREC_F32 if eng.precision == "f32" else H.PREC_F16X3
+        aprec = H.PREC_F32 if eng.precision == "f32" else H.PREC_F16X3   # (bf16 mode too: fp32-grade scores)
         self.steps.append((eng.lib.ddpm3d_attention_p,
                            [H.ptr(qkv.buf), N, x.voxels, heads, ch, aprec, H.ptr(qb) + 4, 32, 2, H.ptr(a.buf), 0]))
         self.release(qkv)

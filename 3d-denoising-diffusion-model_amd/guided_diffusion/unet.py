@@ -237,6 +237,14 @@ class UNetModel_noatt(nn.Module):
         self.dtype = torch.float16
         self.conv_precision = "f16"
 
+    def convert_to_bf16(self):
+        """BASELINE config 4's arithmetic (no counterpart in the reference, which has fp16 only):
+        bf16 operands on the matrix cores and the residual stream stored in bf16, with the fp16
+        mode's placement otherwise -- GroupNorm statistics, timestep path, first conv's inputs and
+        the final conv's output in fp32 (unet.py:999-1005, :1035, :1043)."""
+        self.dtype = torch.bfloat16
+        self.conv_precision = "bf16"
+
     def convert_to_fp32(self):
         self.dtype = torch.float32
         self.conv_precision = os.environ.get("DDPM3D_PRECISION", "f16x3")

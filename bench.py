@@ -56,6 +56,9 @@ PEAK_OF_TAG = {
                                        "(3 split products x 2/3 Winograd F(2,3) along depth)"),
     "p4": (PEAK_F16_MFMA_TFLOPS * 1.5, "f16 MFMA dense (2500) x 3/2 (Winograd F(2,3) along depth issues "
                                        "2/3 MFMA per algorithmic product)"),
+    "p5": (PEAK_F16_MFMA_TFLOPS, "bf16 MFMA dense (2500), 1 MFMA per product"),
+    "p6": (PEAK_F16_MFMA_TFLOPS * 1.5, "bf16 MFMA dense (2500) x 3/2 (Winograd F(2,3) along depth issues "
+                                       "2/3 MFMA per algorithmic product)"),
 }
 
 
@@ -74,6 +77,10 @@ ARITH = {
     "f16": ("f16 operands, f32 accumulate/storage",
             "conv operands rounded to f16 (one MFMA per product), fp32 accumulation, storage, "
             "GroupNorm and timestep path: the reference's --use_fp16 analogue", "f16 MFMA dense"),
+    "bf16": ("bf16",
+             "conv operands rounded to bf16 (one bf16 MFMA per product) and the residual stream stored in "
+             "bf16; fp32 accumulation, GroupNorm statistics, timestep path, network input and output",
+             "bf16 MFMA dense"),
 }
 
 
@@ -144,7 +151,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for cpu_baseline")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--precision", choices=["f32", "f16x3", "f16"],
+    ap.add_argument("--precision", choices=["f32", "f16x3", "f16", "bf16"],
                     default=os.environ.get("DDPM3D_PRECISION", "f16x3"),
                     help="arithmetic of the conv products (all keep fp32 data and accumulators); "
                          "f16 = the reference's --use_fp16 analogue (BASELINE config 4)")
@@ -202,7 +209,7 @@ def main():
     # roofline peak for the dominant kernel's arithmetic: fp32 MFMA; f16 MFMA / 3 (three f16
     # MFMAs per algorithmic fp32 product); f16 MFMA (one per product)
     peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0,
-            "f16": PEAK_F16_MFMA_TFLOPS}[args.precision]
+            "f16": PEAK_F16_MFMA_TFLOPS, "bf16": PEAK_F16_MFMA_TFLOPS}[args.precision]
     B, S = args.batch, args.size
     shape = (B, 1, S, S, S)
     lr = torch.from_numpy(np.stack([synth.synth_low_res((1, S, S, S), seed=1234 + rank * 1000 + b)

@@ -130,8 +130,20 @@ typedef struct ddpm3d_conv_desc {
     int32_t in_bound_count;
     const float* in_bound;
     int32_t in_bound_stride;
-    int32_t reserved0;
+    /* DDPM3D_IO_* bits: which of the activation tensors hold bf16 instead of fp32 elements (same
+     * NDHWC layout, 2 bytes per element, 8-byte aligned).  Statistics, affine tables, bias and
+     * the NCDHW output are fp32 always.  This is the bf16 mode's placement of the reference's
+     * fp16 torso (unet.py:999-1005, :1035, :1043): the residual stream in 16 bits, GroupNorm and the
+     * edges of the network in fp32. */
+    int32_t io_dtype;
 } ddpm3d_conv_desc;
+
+enum {
+    DDPM3D_IO_SRC0_BF16 = 1,
+    DDPM3D_IO_SRC1_BF16 = 2,
+    DDPM3D_IO_OUT_BF16 = 4,    /* with DDPM3D_OUT_NDHWC only */
+    DDPM3D_IO_RES_BF16 = 8
+};
 
 /* ddpm3d_conv_desc.kernel_hint */
 enum {
@@ -167,7 +179,12 @@ enum {
     /* F16 arithmetic (one MFMA per product on f16-rounded operands, as DDPM3D_PREC_F16) on the
      * same Winograd-D form and the same packed image as DDPM3D_PREC_F16X3_WZ (its hi halves);
      * same availability rule. */
-    DDPM3D_PREC_F16_WZ = 4
+    DDPM3D_PREC_F16_WZ = 4,
+    /* One bf16 MFMA per product on bf16-ROUNDED operands (8 significant bits), fp32 accumulate: the
+     * arithmetic BASELINE config 4 names.  bf16 has fp32's exponent range, so no scaling and no
+     * in_bound; judged by PSNR like DDPM3D_PREC_F16.  Own packed image (hi parts only). */
+    DDPM3D_PREC_BF16 = 5,
+    DDPM3D_PREC_BF16_WZ = 6    /* the same on the Winograd-D form; availability as F16X3_WZ */
 };
 
 /* bytes of the packed form of an (Cout, Cin, k, k, k) weight for a precision mode */

@@ -28,7 +28,7 @@ def pack(w, precision=0):
 
 def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res=None, res_mode=H.RES_NONE,
            out_layout=H.OUT_NDHWC, want_stats=True, planar=False, bias_stride_n=0, precision=0, hint=0,
-           bound=None):
+           bound=None, out_bf16=False):
     """srcs: list of NDHWC device tensors (or two (N,1,D,H,W) volumes when planar).
     bound: [N, k] device tensor of upper bounds of the input as the matrix cores see it
     (ddpm3d_conv_desc.in_bound); default = the exact maximum of |act(A*x + B)| per sample.
@@ -49,6 +49,9 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
         if len(srcs) > 1:
             d.src1, d.C1 = H.ptr(srcs[1]), srcs[1].shape[-1]
         d.Cin = d.C0 + d.C1
+        # bf16 tensors are recognised by their dtype (ddpm3d_conv_desc.io_dtype)
+        d.io_dtype |= H.IO_SRC0_BF16 if srcs[0].dtype == torch.bfloat16 else 0
+        d.io_dtype |= H.IO_SRC1_BF16 if (len(srcs) > 1 and srcs[1].dtype == torch.bfloat16) else 0
     assert d.Cin == ci
     if aff is not None:
         d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
@@ -60,7 +63,7 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
             if planar:
                 xin = torch.stack([srcs[0].reshape(N, -1), srcs[1].reshape(N, -1)], dim=-1)
             else:
-                xin = torch.cat([s.reshape(N, -1, s.shape[-1]) for s in srcs], dim=-1)
+                xin = torch.cat([s.float().reshape(N, -1, s.shape[-1]) for s in srcs], dim=-1)
             if aff is not None:
                 xin = xin * aff[0].reshape(N, 1, -1) + aff[1].reshape(N, 1, -1)
                 if act == H.ACT_SILU:
@@ -71,8 +74,13 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
     wp = pack(w, precision)
     d.w_packed, d.bias, d.bias_stride_n = H.ptr(wp), H.ptr(b), bias_stride_n
     d.res_mode, d.res = res_mode, H.ptr(res)
+    if res is not None and res.dtype == torch.bfloat16:
+        d.io_dtype |= H.IO_RES_BF16
+    if out_bf16:
+        d.io_dtype |= H.IO_OUT_BF16
     if out_layout == H.OUT_NDHWC:
-        out = torch.full((N, D, Hh, W, co), float("nan"), dtype=torch.float32, device=dev)
+        out = torch.full((N, D, Hh, W, co), float("nan"), dtype=torch.bfloat16 if out_bf16 else torch.float32,
+                         device=dev)
     else:
         out = torch.full((N, co, D, Hh, W), float("nan"), dtype=torch.float32, device=dev)
     d.out, d.out_layout = H.ptr(out), out_layout

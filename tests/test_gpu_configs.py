@@ -7,9 +7,10 @@ on the GPU, through the HIP engine:
       bar (1e-3), in the exact-fp32 and in the default f16x3 arithmetic;
   C3  one GPU's share of the 8-GPU run: 8 volumes of 64^3 in one launch train, each equal to
       its batch-1 result;
-  C4  50-step DDIM (respace.py "ddim50"), published architecture, 1x64^3, convert_to_fp16();
+  C4  50-step DDIM (respace.py "ddim50"), published architecture, 1x64^3, in the bf16 mode the
+      config names (convert_to_bf16()) and in the reference's own reduced precision (convert_to_fp16());
   C5  1x128^3 with attention at ds 8 (T = 32 768 tokens): full-size properties;
-  and the kernel that only full-size grids select (conv3d_wzs_kernel, 128->128 @ 64^3)
+  and the 64^3-level Winograd layers (128->128, 256->128 concat, upsampled input)
   checked DIRECTLY against F.conv3d on the CPU.
 
 Full-size cases cannot be compared with the CPU oracle inside a test (a published-architecture
@@ -98,6 +99,25 @@ def test_c4_ddim50_published_fp16_mode_psnr():
     psnr = 10 * np.log10(4.0 / max(mse, 1e-30))
     print("config 4 (ddim50, f16 operands) PSNR vs f16x3: %.1f dB" % psnr)
     assert psnr > 45.0, psnr
+
+
+def test_c4_ddim50_published_bf16_mode_psnr():
+    """BASELINE config 4 AS WRITTEN: published architecture, 1x64^3, "ddim50", eta 0, bf16 -- operands
+    rounded to bf16 on the matrix cores and the residual stream stored in bf16
+    (model.convert_to_bf16()).  PSNR against the fp32-grade default mode on the same noise; bf16 has
+    8 significant bits, so the bar is lower than the fp16 mode's."""
+    shape = (1, 1, 64, 64, 64)
+    draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, 51, seed=10)]
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234)).cuda()
+    model, diff = build(PUBLISHED, "ddim50")
+    ref = diff.ddim_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
+    model.convert_to_bf16()
+    out = diff.ddim_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
+    assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6
+    mse = float(((out - ref) ** 2).mean())
+    psnr = 10 * np.log10(4.0 / max(mse, 1e-30))
+    print("config 4 (ddim50, bf16 operands + bf16 residual stream) PSNR vs f16x3: %.1f dB" % psnr)
+    assert psnr > 30.0, psnr            # measured 36.6 dB
 
 
 def test_c5_full_size_attention_forward_properties():

@@ -175,6 +175,30 @@ def test_convert_to_fp16_ddim_psnr(golden):
     assert all(v.dtype == torch.float32 for v in model.state_dict().values())
 
 
+def test_bf16_mode_ddim_psnr(golden):
+    """BASELINE config 4's arithmetic on the tiny net: model.convert_to_bf16() -- bf16 operands on the
+    matrix cores AND the residual stream stored in bf16 (fp32 statistics, timestep path, network input
+    and output).  Judged by PSNR against the fp32 REFERENCE output like the fp16 mode (SURVEY F6);
+    bf16 carries 8 significant bits against f16's 11, so the bar sits ~18 dB lower."""
+    model, diff = build(TINY, "ddim10")
+    model.convert_to_bf16()
+    assert model.dtype == torch.bfloat16 and model.conv_precision == "bf16"
+    shape = (2, 1, 8, 16, 16)
+    draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, 11, seed=10)]
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234)).cuda()
+    out = diff.ddim_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
+    assert out.dtype == torch.float32 and torch.isfinite(out).all()
+    ref = golden("sampler.npz")["ddim10_8x16x16/sample"]
+    mse = float(((out.cpu().numpy() - ref) ** 2).mean())
+    psnr = 10 * np.log10(4.0 / mse)            # data range [-1, 1]
+    print("bf16 mode, tiny net, ddim10: PSNR vs the reference's fp32 output %.1f dB" % psnr)
+    assert psnr > 30.0, psnr            # measured 35.7 dB
+    assert all(v.dtype == torch.float32 for v in model.state_dict().values())
+    # the plan really stores the residual stream in bf16
+    plan = next(iter(model.engine().plans.values()))
+    assert plan.bf16 and any(b.dtype == torch.bfloat16 for b in plan.keep if isinstance(b, torch.Tensor))
+
+
 def test_p_sample_loop_api_and_determinism():
     """Positional noise argument as scripts/test.py:63-69 passes it; result shape/dtype/device;
     bitwise repeatability with injected noise (no atomics anywhere in the path)."""

@@ -202,6 +202,70 @@ def test_conv3d_f16_winograd_depth_form(hc, N, D, Hh, W, ci, co):
     assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(xi, wi, bi, padding=1))
 
 
+@pytest.mark.parametrize("precision,N,D,Hh,W,ci,co", [
+    (5, 1, 4, 16, 16, 64, 128),       # direct form
+    (5, 1, 9, 4, 4, 32, 96),          # 4x4 tiles, partial cout tile
+    (5, 1, 64, 4, 4, 512, 384),       # split-K + reduce kernel
+    (6, 1, 4, 16, 16, 64, 128),       # Winograd-D form
+    (6, 2, 5, 8, 24, 32, 256),        # odd D, batch 2, two cout blocks
+    (6, 1, 64, 8, 8, 256, 384),       # Winograd-D + split-K
+])
+def test_conv3d_bf16_mode(hc, precision, N, D, Hh, W, ci, co):
+    """precisions 5 / 6: one bf16 MFMA per product on bf16-rounded operands (8 significant bits), fp32
+    accumulate -- BASELINE config 4's arithmetic.  Bar: ~2^-9 per operand over a random-sign sum, a
+    few 1e-3 of the output range (f16 mode: ~3e-4); far below 'wrong' (a dropped tap is > 1e-1).
+    No scaling and no in_bound in this mode: bf16 has fp32's exponent range."""
+    x = rnd(N, ci, D, Hh, W, seed=41) * 300.0           # far outside f16's comfortable range
+    w = rnd(co, ci, 3, 3, 3, seed=42, scale=0.03)
+    b = rnd(co, seed=43)
+    ref = F.conv3d(x, w, b, padding=1)
+    bound = torch.full((N, 1), float("nan"), device="cuda")     # ignored by the bf16 modes
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (D, Hh, W), precision=precision,
+                              bound=bound)
+    e = rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy())
+    assert 1e-5 < e < 1e-2, e
+    check_stats(stats, hc.to_ncdhw(out.cpu()))
+    # small integers are exact in bf16 too (|v| <= 256): same mapping as every other mode
+    g = np.random.default_rng(7)
+    xi = torch.from_numpy(g.integers(-3, 4, (1, 16, 4, 9, 10)).astype(np.float32))
+    wi = torch.from_numpy((2 * g.integers(-2, 3, (128, 16, 3, 3, 3))).astype(np.float32))
+    bi = torch.from_numpy(g.integers(-5, 6, (128,)).astype(np.float32))
+    out, _, _ = hc.conv3d([hc.to_ndhwc(xi).cuda()], wi.cuda(), bi.cuda(), (4, 9, 10), precision=precision,
+                          bound=bound)
+    assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(xi, wi, bi, padding=1))
+
+
+@pytest.mark.parametrize("precision", [0, 3, 5, 6])
+def test_conv3d_bf16_tensors(hc, precision):
+    """ddpm3d_conv_desc.io_dtype: sources (virtual concat of a bf16 and an fp32 tensor), residual and
+    output stored in bf16 -- the bf16 mode's residual stream.  The kernel must read exactly the
+    bf16 values (checked against torch on the same rounded tensors) and round its result to
+    nearest-even bf16; statistics are taken BEFORE that rounding (fp32)."""
+    import guided_diffusion._hip as H
+    N, D, Hh, W = 2, 5, 16, 16
+    x0 = rnd(N, 32, D, Hh, W, seed=51).bfloat16()
+    x1 = rnd(N, 32, D, Hh, W, seed=52)
+    res = rnd(N, 128, D, Hh, W, seed=53).bfloat16()
+    w = rnd(128, 64, 3, 3, 3, seed=54, scale=0.05)
+    b = rnd(128, seed=55)
+    A = 1.0 + 0.1 * rnd(N, 64, seed=56)
+    B = 0.1 * rnd(N, 64, seed=57)
+    xin = torch.cat([x0.float(), x1], 1)
+    xin = F.silu(xin * A[:, :, None, None, None] + B[:, :, None, None, None])
+    ref = F.conv3d(xin, w, b, padding=1) + res.float()
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(x0).cuda(), hc.to_ndhwc(x1).cuda()], w.cuda(), b.cuda(), (D, Hh, W),
+                              aff=(A.cuda(), B.cuda()), act=H.ACT_SILU, res=hc.to_ndhwc(res).cuda(),
+                              res_mode=H.RES_SAME, precision=precision, out_bf16=True)
+    assert out.dtype == torch.bfloat16
+    got = hc.to_ncdhw(out.cpu().float())
+    tol = 2e-5 if precision in (0, 3) else 1e-2
+    # the stored value is the fp32 result rounded to bf16: half a bf16 ulp = 2^-9 relative
+    assert rel_err(got.numpy(), ref.numpy()) < tol + 2.0 ** -8
+    if precision in (0, 3):
+        assert rel_err(got.numpy(), ref.bfloat16().float().numpy()) < 2.0 ** -7 * 1.01   # at most one bf16 ulp apart
+        check_stats(stats, ref)
+
+
 def test_conv3d_k1_concat(hc):
     xa, xb = rnd(2, 32, 3, 8, 8, seed=1), rnd(2, 16, 3, 8, 8, seed=2)
     w = rnd(64, 48, 1, 1, 1, seed=3, scale=0.1)

@@ -71,7 +71,8 @@ def test_conv_desc_struct_layout_matches_header():
     assert f["w_packed"] == 80 and f["bias_stride_n"] == 96 and f["res"] == 104 and f["out"] == 112
     assert f["out_layout"] == 120 and f["stats"] == 128 and f["workspace"] == 136
     assert f["workspace_bytes"] == 144 and f["kernel_hint"] == 152 and f["in_bound_count"] == 156
-    assert f["in_bound"] == 160 and f["in_bound_stride"] == 168 and ctypes.sizeof(_hip.ConvDesc) == 176
+    assert f["in_bound"] == 160 and f["in_bound_stride"] == 168 and f["io_dtype"] == 172
+    assert ctypes.sizeof(_hip.ConvDesc) == 176
 
 
 def test_sr_defaults_and_flag_parsing():
