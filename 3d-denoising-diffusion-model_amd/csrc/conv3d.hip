@@ -447,8 +447,9 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     constexpr size_t lds = (size_t)WzGeom::BUF;
     // One kernel form.  Measured and dropped in r02 (profiles/r02_layer_ab_*.txt): a
     // wave-specialised persistent form (compute waves + loader waves, tile walk, epilogue hand-off
-    // through LDS) and a 128-row wave tile with one wave per SIMD -- both 3-15 % behind this one
-    // once the staging was cut to ~330 instructions per item (conv3d_stage.h).
+    // through LDS) and a 128-row wave tile with one wave per SIMD (plain, and with the staging
+    // interleaved into the tap loop) -- all 3-15 % behind this one once the staging was cut to ~400
+    // instructions per item (conv3d_stage.h).
     if (c.PREC == DDPM3D_PREC_F16_WZ)
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     else if (c.PREC == DDPM3D_PREC_BF16_WZ)

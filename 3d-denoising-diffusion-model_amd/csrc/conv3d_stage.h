@@ -203,3 +203,4 @@ __device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<
         }
     }
 }
+

@@ -32,7 +32,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1)
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16", "bf16"])
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
