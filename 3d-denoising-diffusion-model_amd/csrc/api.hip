@@ -80,7 +80,9 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         if (d->Cin != 2 || d->C0 != 1 || d->C1 != 1 || !d->src1 || d->aff_a)
             return fail(DDPM3D_EINVAL, "conv3d: planar2 input needs C0=C1=1, two planes, no affine");
     } else {
-        if (d->in_mode < 0 || d->in_mode > 3) return fail(DDPM3D_EINVAL, "conv3d: in_mode %d", d->in_mode);
+        if (d->in_mode < 0 || d->in_mode > DDPM3D_IN_STRIDE2) return fail(DDPM3D_EINVAL, "conv3d: in_mode %d", d->in_mode);
+        if (d->in_mode == DDPM3D_IN_STRIDE2 && d->ksize != 3)
+            return fail(DDPM3D_EINVAL, "conv3d: the strided input mode is the 3x3x3 Downsample conv's");
         if (d->Cin % DDPM3D_CONV_CK) return fail(DDPM3D_EINVAL, "conv3d: Cin=%d not a multiple of %d", d->Cin, DDPM3D_CONV_CK);
         if (d->C1 > 0 && (d->C0 % DDPM3D_CONV_CK || !d->src1))
             return fail(DDPM3D_EINVAL, "conv3d: concat needs C0 %% %d == 0 and src1", DDPM3D_CONV_CK);
@@ -145,8 +147,9 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     k.partial = (float*)d->workspace;
     {
         // extents for the kernel's buffer descriptors (32-bit offsets)
-        const long long Hs = d->in_mode == DDPM3D_IN_POOL ? 2LL * d->H : (d->in_mode == DDPM3D_IN_UP ? d->H / 2 : d->H);
-        const long long Ws = d->in_mode == DDPM3D_IN_POOL ? 2LL * d->W : (d->in_mode == DDPM3D_IN_UP ? d->W / 2 : d->W);
+        const bool dbl = d->in_mode == DDPM3D_IN_POOL || d->in_mode == DDPM3D_IN_STRIDE2;
+        const long long Hs = dbl ? 2LL * d->H : (d->in_mode == DDPM3D_IN_UP ? d->H / 2 : d->H);
+        const long long Ws = dbl ? 2LL * d->W : (d->in_mode == DDPM3D_IN_UP ? d->W / 2 : d->W);
         const long long vox = (long long)d->N * d->D * Hs * Ws;
         const long long b0 = vox * d->C0 * ((d->io_dtype & DDPM3D_IO_SRC0_BF16) ? 2 : 4);
         const long long b1 = vox * d->C1 * ((d->io_dtype & DDPM3D_IO_SRC1_BF16) ? 2 : 4);

@@ -37,16 +37,19 @@
 #include "conv3d_load.h"
 #include "conv3d_epilogue.h"  // LdsGeom, conv_epilogue
 
-// PIPE = 1: IN_SAME / IN_UP inputs, staging software-pipelined; PIPE = 0: IN_POOL / IN_PLANAR2.
-template <int PREC, int PIPE, int KS, int WN, int MT, int TXL, int TYL>
-__global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const ConvK p) {
+// PIPEM = 1: IN_SAME / IN_UP inputs, staging software-pipelined; 0: IN_POOL / IN_PLANAR2;
+// 2: IN_STRIDE2 (stride (1,2,2): the halo tile is laid out in the source grid, rows 2 voxels apart).
+template <int PREC, int PIPEM, int KS, int WN, int MT, int TXL, int TYL>
+__global__ __launch_bounds__(256, (PIPEM == 2 ? 1 : (TXL == 2 ? 2 : 3))) void conv3d_kernel(const ConvK p) {
     constexpr int CK = DDPM3D_CONV_CK;
+    constexpr int PIPE = PIPEM == 1 ? 1 : 0;
+    constexpr int SXY = PIPEM == 2 ? 2 : 1;           // stride along H and W
     constexpr int WM = 4 / WN;
     // MT = 32-row accumulators per wave; workgroup tile = WM * MT * 32 voxels = 128
     constexpr int TX = 1 << TXL, TY = 1 << TYL;
     constexpr int TZ = WM * MT * 32 / (TX * TY);
     constexpr int PAD = KS / 2;
-    constexpr int HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = TZ + 2 * PAD;
+    constexpr int HX = SXY * (TX - 1) + KS, HY = SXY * (TY - 1) + KS, HZ = TZ + 2 * PAD;
     constexpr int HV = HX * HY * HZ;
     // LDS image of the halo tile.  One voxel = 80 bytes = 5 slots of 16 B in both modes:
     //   PREC 0: 16 floats + 4 pad;  PREC 1: 16 f16 hi | 16 f16 lo | 8 f16 pad.
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
     for (int t = 0; t < MT; ++t) {
         const int m = (wm * MT + t) * 32 + (lane & 31);
         const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
-        arow[t] = (tz * RZ + ty * RY + tx * VS + half) * 16;
+        arow[t] = (tz * RZ + SXY * ty * RY + SXY * tx * VS + half) * 16;
     }
 
     const int cout = wg.cy * (32 * WN) + wn * 32 + (lane & 31);
@@ -203,8 +206,8 @@ __global__ __launch_bounds__(256, (TXL == 2 ? 2 : 3)) void conv3d_kernel(const C
                     const int rem = hv - hz * (HY * HX);
                     const int hy = rem / HX;
                     const int hx = rem - hy * HX;
-                    store_item(hz, hy, hx, halo_fetch<PREC != 0>(p, hs, n, z0 - PAD + hz, y0 - PAD + hy,
-                                                                 x0 - PAD + hx, q, chunk == 0));
+                    store_item(hz, hy, hx, halo_fetch<PREC != 0>(p, hs, n, z0 - PAD + hz, SXY * y0 - PAD + hy,
+                                                                 SXY * x0 - PAD + hx, q, chunk == 0));
                 }
             }
         }
@@ -464,9 +467,15 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
 template <int PREC, int PIPE, int KS, int WN, int MT, int TXL, int TYL>
 static hipError_t launch_cfg(const ConvK& k, int grid_x, int grid_y, hipStream_t st) {
     constexpr int TX = 1 << TXL, TY = 1 << TYL, TZ = (4 / WN) * MT * 32 / (TX * TY);
-    constexpr int PAD = KS / 2;
-    constexpr int HX = TX + 2 * PAD, HY = TY + 2 * PAD, HZ = TZ + 2 * PAD;
+    constexpr int PAD = KS / 2, SXY = PIPE == 2 ? 2 : 1;
+    constexpr int HX = SXY * (TX - 1) + KS, HY = SXY * (TY - 1) + KS, HZ = TZ + 2 * PAD;
     constexpr size_t lds_bytes = (size_t)HZ * LdsGeom<TX, HX, HY>::RZ * 16;
+    if constexpr (lds_bytes > 65536) {
+        static const hipError_t attr = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&conv3d_kernel<PREC, PIPE, KS, WN, MT, TXL, TYL>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (attr != hipSuccess) return attr;
+    }
     hipLaunchKernelGGL((conv3d_kernel<PREC, PIPE, KS, WN, MT, TXL, TYL>), dim3(grid_x, grid_y, k.ksplit), dim3(256),
                        lds_bytes, st, k);
     return hipGetLastError();
@@ -477,7 +486,7 @@ static hipError_t launch_cfg(const ConvK& k, int grid_x, int grid_y, hipStream_t
 hipError_t DDPM3D_CAT(ddpm3d_launch_conv_p, DDPM3D_PREC_ONLY)(const ConvK& k, const ConvCfg& c, hipStream_t st) {
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     const int gy = (k.CoutPad + 32 * c.WN - 1) / (32 * c.WN);
-    const int pipe = (k.in_mode == DDPM3D_IN_SAME || k.in_mode == DDPM3D_IN_UP) ? 1 : 0;
+    const int pipe = k.in_mode == DDPM3D_IN_STRIDE2 ? 2 : ((k.in_mode == DDPM3D_IN_SAME || k.in_mode == DDPM3D_IN_UP) ? 1 : 0);
 #define CASE(P_, PI_, KS_, WN_, MT_, TXL_, TYL_)                                                      \
     if (pipe == PI_ && c.KS == KS_ && c.WN == WN_ && c.MT == MT_ && c.TXL == TXL_ && c.TYL == TYL_)   \
         return launch_cfg<P_, PI_, KS_, WN_, MT_, TXL_, TYL_>(k, gx, gy, st);
@@ -487,6 +496,9 @@ hipError_t DDPM3D_CAT(ddpm3d_launch_conv_p, DDPM3D_PREC_ONLY)(const ConvK& k, co
     CASE(P_, PI_, 1, 4, 4, 3, 3) CASE(P_, PI_, 1, 2, 2, 3, 3) CASE(P_, PI_, 1, 1, 1, 3, 3)      \
     CASE(P_, PI_, 1, 4, 4, 2, 2) CASE(P_, PI_, 1, 2, 2, 2, 2) CASE(P_, PI_, 1, 1, 1, 2, 2)
     CASES(DDPM3D_PREC_ONLY, 1) CASES(DDPM3D_PREC_ONLY, 0)
+    // stride-(1,2,2) 3x3x3 convs (Downsample with use_conv)
+    CASE(DDPM3D_PREC_ONLY, 2, 3, 4, 4, 3, 3) CASE(DDPM3D_PREC_ONLY, 2, 3, 2, 2, 3, 3) CASE(DDPM3D_PREC_ONLY, 2, 3, 1, 1, 3, 3)
+    CASE(DDPM3D_PREC_ONLY, 2, 3, 4, 4, 2, 2) CASE(DDPM3D_PREC_ONLY, 2, 3, 2, 2, 2, 2) CASE(DDPM3D_PREC_ONLY, 2, 3, 1, 1, 2, 2)
 #undef CASES
 #undef CASE
     return hipErrorInvalidValue;

@@ -76,8 +76,9 @@ __device__ __forceinline__ HaloSrc halo_src(const ConvK& p, int n, int chunk, in
     h.src_bytes = from0 ? p.src0_bytes : p.src1_bytes;
     h.Cs = from0 ? p.C0 : p.C1;
     h.cb = from0 ? c0 : c0 - p.C0;
-    h.Hs = p.in_mode == DDPM3D_IN_POOL ? 2 * p.H : (p.in_mode == DDPM3D_IN_UP ? p.H / 2 : p.H);
-    h.Ws = p.in_mode == DDPM3D_IN_POOL ? 2 * p.W : (p.in_mode == DDPM3D_IN_UP ? p.W / 2 : p.W);
+    const bool dbl = p.in_mode == DDPM3D_IN_POOL || p.in_mode == DDPM3D_IN_STRIDE2;
+    h.Hs = dbl ? 2 * p.H : (p.in_mode == DDPM3D_IN_UP ? p.H / 2 : p.H);
+    h.Ws = dbl ? 2 * p.W : (p.in_mode == DDPM3D_IN_UP ? p.W / 2 : p.W);
     h.has_aff = p.affA != nullptr && p.in_mode != DDPM3D_IN_PLANAR2;
     h.ga = f32x4{1.f, 1.f, 1.f, 1.f};
     h.gb = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -92,6 +93,14 @@ template <bool FAST>
 __device__ __forceinline__ f32x4 halo_fetch(const ConvK& p, const HaloSrc& h, int n, int z, int y, int x,
                                             int q, bool first_chunk) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p.in_mode == DDPM3D_IN_STRIDE2) {
+        // (y, x) are coordinates of the SOURCE grid here (the strided conv's halo is laid out in it)
+        if (!((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)h.Hs && (unsigned)x < (unsigned)h.Ws)) return v;
+        const size_t vox = (((size_t)n * p.D + z) * h.Hs + y) * h.Ws + x;
+        v = act_quad(h.src, vox * h.Cs + h.cb + q * 4, h.b16);
+        if (h.has_aff) v = p.act ? affine_act<1, FAST>(v, h.ga, h.gb) : affine_act<0, FAST>(v, h.ga, h.gb);
+        return v;
+    }
     const bool inb = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
     if (!inb) return v;
     if (p.in_mode == DDPM3D_IN_SAME) {

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DDPM3D_LIB: developer override to A/B an experimental build of the same ABI
 LIB_PATH = os.environ.get("DDPM3D_LIB") or os.path.normpath(os.path.join(_HERE, "..", "csrc", "libddpm3d.so"))
 
-IN_SAME, IN_POOL, IN_UP, IN_PLANAR2 = 0, 1, 2, 3
+IN_SAME, IN_POOL, IN_UP, IN_PLANAR2, IN_STRIDE2 = 0, 1, 2, 3, 4
 RES_NONE, RES_SAME, RES_POOL, RES_UP = 0, 1, 2, 3
 ACT_NONE, ACT_SILU = 0, 1
 OUT_NDHWC, OUT_NCDHW = 0, 1

@@ -374,26 +374,16 @@ class _Plan:
         if e.kind == "attn":
             return self.attention(e, srcs[0])
         if e.kind == "downconv":
-            # Downsample(use_conv=True), unet.py:129-133: Conv3d(stride=(1,2,2), padding=1) = the
-            # stride-1 conv kept at the even (y, x).  Full-resolution conv -> subsample ->
-            # statistics for the next GroupNorm (correct, not fast: 3/4 of the conv is discarded;
-            # only reachable with resblock_updown=False, which the published model does not use).
+            # Downsample(use_conv=True), unet.py:129-133: Conv3d(stride=(1,2,2), padding=1), the
+            # factory's default resampling (resblock_updown=False).  One strided conv launch (the halo
+            # tile is laid out in the source grid); its epilogue emits the statistics of the result.
             x = srcs[0]
             if (x.H | x.W) & 1:
                 raise RuntimeError("Downsample needs even H, W (got %dx%d)" % (x.H, x.W))
             pc = eng.conv[e.prefix + ".op"]
-            lib, N = eng.lib, self.N
-            full = self.new_act(pc.Cout, x.D, x.H, x.W, fp32=True)      # read by ddpm3d_subsample_hw2
+            y = self.new_act(pc.Cout, x.D, x.H // 2, x.W // 2)
             _, _, bnd = self.finalize([x], None, None)
-            self.conv_step(pc, [x], full, want_stats=False, bound=(bnd, 1, 32, 2))
-            y = self.new_act(pc.Cout, x.D, x.H // 2, x.W // 2, fp32=True)   # read by ddpm3d_gn_stats
-            self.steps.append((lib.ddpm3d_subsample_hw2,
-                               [H.ptr(full.buf), N, x.D, x.H, x.W, pc.Cout, H.ptr(y.buf), 0]))
-            y.rows = lib.ddpm3d_gn_stats_rows(y.voxels)
-            y.stats = torch.empty(N * y.rows * pc.Cout * 2, dtype=torch.float32, device=eng.device)
-            self.keep.append(y.stats)
-            self.steps.append((lib.ddpm3d_gn_stats, [H.ptr(y.buf), N, y.voxels, pc.Cout, H.ptr(y.stats), 0]))
-            self.release(full)
+            self.conv_step(pc, [x], y, in_mode=H.IN_STRIDE2, bound=(bnd, 1, 32, 2))
             return y
         raise ValueError(e.kind)
 

@@ -57,8 +57,10 @@ enum {
                               after norm+act and before the conv, unet.py:237-242      */
     DDPM3D_IN_UP = 2,      /* source is D,H/2,W/2; nearest (y>>1, x>>1) -- Upsample,
                               unet.py:102-105                                          */
-    DDPM3D_IN_PLANAR2 = 3  /* src0, src1 are two single-channel NCDHW volumes (x and
+    DDPM3D_IN_PLANAR2 = 3, /* src0, src1 are two single-channel NCDHW volumes (x and
                               low_res, unet.py:1690-1693); Cin = 2                     */
+    DDPM3D_IN_STRIDE2 = 4  /* source is D,2H,2W and the conv has stride (1,2,2), pad 1:
+                              Downsample(use_conv=True), unet.py:129-133 (ksize 3)     */
 };
 
 /* residual modes of the conv epilogue (out = conv + bias + residual) */

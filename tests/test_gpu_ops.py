@@ -536,6 +536,30 @@ def test_sampler_update_kernels(hc, learn, xstart, clip):
             assert rel_err(got2["sample"].cpu().numpy(), ref2.numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("N,D,Hh,W,ci,co,precision", [
+    (1, 4, 16, 16, 32, 32, 0),       # tiny net's widths, one 8x8 output tile
+    (2, 5, 24, 12, 32, 48, 1),       # ragged output tiles (12x6), batch 2, partial cout tile
+    (1, 9, 8, 8, 64, 160, 1),        # 4x4 output tiles, two cout blocks
+    (1, 4, 32, 32, 128, 128, 1),     # published widths
+    (1, 4, 32, 32, 128, 128, 5),     # bf16 arithmetic
+])
+def test_conv3d_strided_downsample(hc, N, D, Hh, W, ci, co, precision):
+    """DDPM3D_IN_STRIDE2: Downsample(use_conv=True) = Conv3d(stride=(1,2,2), padding=1) (unet.py:129-133)
+    in ONE launch on the half-resolution output grid (r01 ran the full-resolution conv and kept a
+    quarter of it), with the GroupNorm statistics of the result from the same epilogue."""
+    import guided_diffusion._hip as H
+    x = rnd(N, ci, D, Hh, W, seed=71)
+    w = rnd(co, ci, 3, 3, 3, seed=72, scale=0.05)
+    b = rnd(co, seed=73)
+    ref = F.conv3d(x, w, b, stride=(1, 2, 2), padding=1)
+    assert ref.shape[-2:] == (Hh // 2, W // 2)
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (D, Hh // 2, W // 2),
+                              in_mode=H.IN_STRIDE2, precision=precision)
+    got = hc.to_ncdhw(out.cpu())
+    assert rel_err(got.numpy(), ref.numpy()) < (1e-2 if precision == 5 else TOL)
+    check_stats(stats, got)
+
+
 def test_strided_downsample_conv_as_conv_plus_subsample(hc):
     """Downsample(use_conv=True) (unet.py:129-133): Conv3d(stride=(1,2,2), padding=1) equals the
     stride-1 conv kept at the even (y, x) -- conv3d + ddpm3d_subsample_hw2, then ddpm3d_gn_stats."""
