@@ -80,6 +80,7 @@ class UNetEngine:
         self.film = film  # use_scale_shift_norm
         self.p = params    # name -> device fp32 tensor
         self.plans = collections.OrderedDict()   # (N, D, H, W) -> _Plan, least recently used first
+        self.split_above = {}                    # (D, H, W) -> largest batch one launch can address
         st = H.stream()
         self.conv = {}
         self.winograd = os.environ.get("DDPM3D_WINOGRAD", "1") != "0"
@@ -162,8 +163,33 @@ class UNetEngine:
         (stride film_stride floats; 0 = one row shared by the batch) holds the
         fused emb_layers output for sample n.  Returns (N, Cout, D, H, W)."""
         N, _, D, Hh, W = x.shape
+        # The kernels address a tensor with 32-bit byte offsets and the C ABI refuses (before
+        # launching anything for that conv) a batch whose tensors pass 4 GiB: such a batch runs as
+        # two halves, recursively (>= 32 volumes of 64^3 on the published network).
+        if N > self.split_above.get((D, Hh, W), 1 << 30):
+            return self._forward_halves(x, low_res, film_rows, film_stride, out)
         pl = self.plan(N, D, Hh, W)
-        return pl.run(x, low_res, film_rows, film_stride, out)
+        try:
+            return pl.run(x, low_res, film_rows, film_stride, out)
+        except RuntimeError as e:
+            if N == 1 or "exceed 4 GiB" not in str(e):
+                raise
+        self.plans.pop((N, D, Hh, W), None)
+        self.split_above[(D, Hh, W)] = min(self.split_above.get((D, Hh, W), 1 << 30), N - 1)
+        return self._forward_halves(x, low_res, film_rows, film_stride, out)
+
+    def _forward_halves(self, x, low_res, film_rows, film_stride, out):
+        N = x.shape[0]
+        res = out
+        h = (N + 1) // 2
+        for a, b in ((0, h), (h, N)):
+            rows = film_rows if film_stride == 0 else film_rows.reshape(-1)[a * film_stride:]
+            part = self.forward(x[a:b].contiguous(), low_res[a:b].contiguous(), rows, film_stride,
+                                None if res is None else res[a:b])
+            if res is None:
+                res = torch.empty((N,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+                res[a:b] = part
+        return res
 
 
 class _Plan:

@@ -3,11 +3,13 @@ Whole-body volume <-> 96^3 sub-volume patches: the steps either side of the
 sampling hot path in the reference's inference script.
 
 Restated from scripts/test.py:185-246 (tiling), :248-262 (3-D Hann window),
-:92-146 (weighted overlap-add) and :283-301 (start positions).  PARITY
-UNPINNED: scripts/test.py cannot be imported in the build container (it needs
-tifffile / mpi4py) and the reference holds no fixtures for it, so these
-functions are checked against the constants and invariants the source states
-(tests/test_patches_cpu.py), not against reference outputs.
+:92-146 (weighted overlap-add) and :283-301 (start positions).  scripts/test.py
+cannot be imported in the build container (it needs tifffile / mpi4py) and the
+reference holds no fixtures for it.  The three pure helpers (hann_window_3d,
+xy_starts, z_starts) are pinned to outputs of the reference's own function
+bodies (tests/golden/script_helpers.npz); the tiling and overlap-add, inline in
+the reference's main(), are checked against the constants and invariants the
+source states (tests/test_patches_cpu.py) -- PARITY UNPINNED for those.
 
 Host-side numpy on purpose: this is file-format glue around the GPU path (a
 200x200x130 volume is 5 M voxels), exactly where the reference has it.

@@ -179,8 +179,8 @@ class UNetModel_noatt(nn.Module):
             raise NotImplementedError("the HIP engine implements the 3-D model (dims=3) only")
         if num_classes is not None:
             raise NotImplementedError("class conditioning is unused by the 3-D PET model")
-        if dropout:
-            raise NotImplementedError("dropout is a training-time feature; sampling uses p=0")
+        # dropout: nn.Dropout is the identity in eval mode (unet.py:209), and this package only
+        # samples -- any p is accepted and ignored
         if not conv_resample and not resblock_updown:
             raise NotImplementedError("conv_resample=False")
         if use_new_attention_order:

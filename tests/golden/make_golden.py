@@ -248,8 +248,43 @@ def gen_sampler_published250():
     save("sampler_published250.npz", **out)
 
 
+def gen_script_helpers():
+    """The pure helpers of the reference's inference script (scripts/test.py:248-262 Hann window,
+    :283-301 patch start positions).  The script itself cannot be imported here (it needs tifffile /
+    mpi4py at import time), so the three function definitions are taken out of its syntax tree and
+    evaluated UNCHANGED, with numpy and the reference's own logger module as their globals -- no
+    stand-in for anything.  Only their outputs are stored."""
+    import ast
+    from guided_diffusion import logger as ref_logger
+    path = "/root/reference/scripts/test.py"
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    want = {"create_3d_hann_window", "_calculate_xy_starts_fixed", "_calculate_z_starts_with_overlap"}
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want],
+                     type_ignores=[])
+    assert {n.name for n in mod.body} == want
+    ns = {"np": np, "logger": ref_logger}
+    exec(compile(mod, path, "exec"), ns)
+    out = {}
+    xy_cases = [(200, 96, 3), (150, 96, 3), (96, 96, 1), (40, 16, 3), (16, 16, 3), (130, 96, 2), (257, 64, 4),
+                (100, 96, 3)]
+    out["xy_cases"] = np.array(xy_cases, dtype=np.int64)
+    out["xy_starts"] = np.array([ns["_calculate_xy_starts_fixed"](*c) + [-1] * (4 - c[2]) for c in xy_cases],
+                                dtype=np.int64)
+    z_cases = [(90, 96), (96, 96), (130, 96), (97, 96), (20, 16), (16, 16)]
+    out["z_cases"] = np.array(z_cases, dtype=np.int64)
+    out["z_starts"] = np.array([(ns["_calculate_z_starts_with_overlap"](*c) + [-1])[:2] for c in z_cases],
+                               dtype=np.int64)
+    for size in (8, 16):
+        out["hann%d" % size] = ns["create_3d_hann_window"](size)
+    w96 = ns["create_3d_hann_window"](96)
+    out["hann96_mid_plane"] = w96[48]
+    out["hann96_stats"] = np.array([w96.min(), w96.max(), w96.mean(), w96.sum()])
+    save("script_helpers.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "temb", "keys", "resblocks", "unet", "sampler"]
+    which = sys.argv[1:] or ["schedules", "temb", "keys", "resblocks", "unet", "sampler", "helpers"]
     if "schedules" in which:
         gen_schedules()
     if "temb" in which:
@@ -262,5 +297,7 @@ if __name__ == "__main__":
         gen_unet_forward()
     if "sampler" in which:
         gen_sampler()
+    if "helpers" in which:
+        gen_script_helpers()
     if "sampler250" in which:       # ~10 CPU-minutes; not part of the default list
         gen_sampler_published250()

@@ -249,6 +249,29 @@ def test_full_size_forward_properties():
     assert rel_err(y_def, y_exact) < 1e-4
 
 
+def test_batch_beyond_32bit_addressing_is_split():
+    """One launch addresses a tensor with 32-bit byte offsets (the C ABI refuses more: "split the
+    batch").  The engine does the splitting: 130 volumes of 64^3 through the tiny net make 4.4 GB
+    full-resolution activations; the forward runs as halves and every volume equals its own
+    batch-1 result."""
+    model, _ = build(TINY)
+    N = 130
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, 1, 64, 64, 64, generator=g)
+    lr = torch.rand(N, 1, 64, 64, 64, generator=g)
+    t = torch.randint(0, 1000, (N,), generator=g)
+    with torch.no_grad():
+        y = model(x.cuda(), t.cuda(), low_res=lr.cuda())
+        assert tuple(y.shape) == (N, 2, 64, 64, 64) and torch.isfinite(y).all()
+        eng = model.engine()
+        assert eng.split_above[(64, 64, 64)] < N          # the refusal was met and handled
+        for n in (0, 64, 65, 129):
+            y1 = model(x[n:n + 1].cuda(), t[n:n + 1].cuda(), low_res=lr[n:n + 1].cuda())
+            assert rel_err(y[n:n + 1].cpu().numpy(), y1.cpu().numpy()) < 2e-5, n
+    del y
+    torch.cuda.empty_cache()
+
+
 def test_cpu_tensors_are_refused():
     model, diff = build(TINY, "10")
     x, lr = inputs((1, 1, 4, 16, 16))

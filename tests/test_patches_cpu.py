@@ -1,14 +1,31 @@
 """
 Patch tiler / Hann stitcher / volume I/O (guided_diffusion/patches.py).
-PARITY UNPINNED against the reference (scripts/test.py cannot be imported here
-and holds no fixtures): checked against the constants its source states and
-against invariants of the algorithm.
+
+The reference script (scripts/test.py) cannot be imported in the build container (tifffile / mpi4py)
+and holds no fixtures.  Its three PURE helpers -- the Hann window and the two start-position rules
+-- are pinned to outputs of the reference's own function bodies (tests/golden/script_helpers.npz,
+tests/golden/make_golden.py::gen_script_helpers); the tiling / overlap-add around them, which the
+reference only has inline in main(), stays checked against the constants its source states and
+against invariants of the algorithm (PARITY UNPINNED for those).
 """
 
 import numpy as np
 import pytest
 
 from guided_diffusion import patches
+
+
+def test_pure_helpers_vs_reference_golden(golden):
+    g = golden("script_helpers.npz")
+    for (dim, patch, n), ref in zip(g["xy_cases"], g["xy_starts"]):
+        assert patches.xy_starts(int(dim), int(patch), int(n)) == [int(v) for v in ref[:n]], (dim, patch, n)
+    for (dim, patch), ref in zip(g["z_cases"], g["z_starts"]):
+        assert patches.z_starts(int(dim), int(patch)) == [int(v) for v in ref if v >= 0], (dim, patch)
+    for size in (8, 16):
+        assert np.array_equal(patches.hann_window_3d(size), g["hann%d" % size])      # same float operations
+    w = patches.hann_window_3d(96)
+    assert np.array_equal(w[48], g["hann96_mid_plane"])
+    assert np.allclose([w.min(), w.max(), w.mean(), w.sum()], g["hann96_stats"], rtol=1e-12, atol=0)
 
 
 def test_start_positions_match_the_reference_constants():
