@@ -235,6 +235,12 @@ int ddpm3d_ndhwc_to_ncdhw(const float* in, int N, int C, int voxels, float* out,
     return launched(ddpm3d_launch_transpose(in, N, voxels, C, out, (hipStream_t)stream), "ndhwc_to_ncdhw");
 }
 
+int ddpm3d_ncdhw_to_ndhwc_pad(const float* in, int N, int C, int voxels, int Cpad, float* out, void* stream) {
+    if (!in || !out || N <= 0 || C <= 0 || voxels <= 0 || Cpad < C)
+        return fail(DDPM3D_EINVAL, "ncdhw_to_ndhwc_pad: bad arguments");
+    return launched(ddpm3d_launch_to_ndhwc_pad(in, N, C, voxels, Cpad, out, (hipStream_t)stream), "ncdhw_to_ndhwc_pad");
+}
+
 int ddpm3d_subsample_hw2(const float* in, int N, int D, int H, int W, int C, float* out, void* stream) {
     if (!in || !out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1) || (C & 3) ||
         !aligned16(in) || !aligned16(out))

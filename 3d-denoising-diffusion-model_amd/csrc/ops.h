@@ -18,6 +18,7 @@ hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, c
 hipError_t ddpm3d_launch_linear(const float* in, int rows, int K, const float* w, const float* bias, int O,
                                 int silu_in, float* out, int out_stride, hipStream_t st);
 hipError_t ddpm3d_launch_transpose(const float* in, int N, int R, int S, float* out, hipStream_t st);
+hipError_t ddpm3d_launch_to_ndhwc_pad(const float* in, int N, int C, int voxels, int Cpad, float* out, hipStream_t st);
 hipError_t ddpm3d_launch_subsample_hw2(const float* in, int N, int D, int H, int W, int C, float* out,
                                        hipStream_t st);
 hipError_t ddpm3d_launch_sample_step(bool ddim, const float* mo, const float* x, const float* noise,

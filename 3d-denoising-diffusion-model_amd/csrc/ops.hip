@@ -481,6 +481,19 @@ __global__ __launch_bounds__(256) void transpose_cv_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void to_ndhwc_pad_kernel(const float* __restrict__ in, int C, int voxels, int Cpad,
+                                                           float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= voxels) return;
+    float* o = out + ((size_t)n * voxels + v) * Cpad;
+    for (int c = 0; c < Cpad; ++c) o[c] = c < C ? in[((size_t)n * C + c) * voxels + v] : 0.0f;
+}
+hipError_t ddpm3d_launch_to_ndhwc_pad(const float* in, int N, int C, int voxels, int Cpad, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(to_ndhwc_pad_kernel, dim3((voxels + 255) / 256, N), dim3(256), 0, st, in, C, voxels, Cpad, out);
+    return hipGetLastError();
+}
+
 hipError_t ddpm3d_launch_transpose(const float* in, int N, int R, int S, float* out, hipStream_t st) {
     dim3 grid((S + 31) / 32, (R + 31) / 32, N);
     hipLaunchKernelGGL(transpose_cv_kernel, grid, dim3(256), 0, st, in, R, S, out);

@@ -70,6 +70,7 @@ EXPORTS = {
                                      _fp, _fp]),
     "ddpm3d_ncdhw_to_ndhwc": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_ndhwc_to_ncdhw": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "ddpm3d_ncdhw_to_ndhwc_pad": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_subsample_hw2": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "ddpm3d_p_sample_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ddpm3d_ddim_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float,

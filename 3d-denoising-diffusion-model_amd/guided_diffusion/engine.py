@@ -21,7 +21,6 @@ for every step of the schedule.
 import collections
 import ctypes as C
 import math
-import os
 
 import torch
 
@@ -65,7 +64,8 @@ class PackedConv:
 class UNetEngine:
     """Executes one model on one device.  `layers` is unet.py's topology."""
 
-    def __init__(self, topo, params, model_channels, film, device, precision="f32"):
+    def __init__(self, topo, params, model_channels, film, device, precision="f32", in_channels=2, planar=True,
+                 winograd=True):
         """precision: "f32" = exact fp32 MFMA everywhere; "f16x3" = every conv evaluates
         each fp32 product as three f16 MFMAs (fp32-equivalent accuracy, see
         include/ddpm3d.h); "f16" = one f16 MFMA per product (the reference's --use_fp16);
@@ -83,11 +83,29 @@ class UNetEngine:
         self.split_above = {}                    # (D, H, W) -> largest batch one launch can address
         st = H.stream()
         self.conv = {}
-        self.winograd = os.environ.get("DDPM3D_WINOGRAD", "1") != "0"
+        self.winograd = winograd
+        # planar: the SuperRes first conv reads x and low_res as two single-channel volumes; otherwise
+        # the input is an ordinary (N, in_channels, ...) tensor, padded to 16 channels at the edge
+        self.planar = planar
+        self.in_channels = in_channels
+        self.cin_pad = (in_channels + 15) // 16 * 16
+        first = topo.input[0][0].prefix
         for name, t in params.items():
             if name.endswith(".weight") and t.dim() >= 3:
                 base = name[:-len(".weight")]
-                w = t if t.dim() == 5 else t.reshape(t.shape[0], t.shape[1], 1, 1, 1)
+                if t.dim() == 5:
+                    w = t
+                elif t.dim() == 4 and t.shape[2] == 3:
+                    # a 2-D 3x3 conv (dims=2 models) = the 3x3x3 conv whose only non-zero depth tap is
+                    # the centre one, on depth-1 volumes
+                    w = torch.zeros(t.shape[0], t.shape[1], 3, 3, 3, dtype=t.dtype, device=t.device)
+                    w[:, :, 1] = t
+                else:                               # Conv1d / 1x1 Conv2d: pointwise
+                    w = t.reshape(t.shape[0], t.shape[1], 1, 1, 1)
+                if base == first and not planar and w.shape[1] != self.cin_pad:
+                    wp = torch.zeros(w.shape[0], self.cin_pad, *w.shape[2:], dtype=w.dtype, device=w.device)
+                    wp[:, :w.shape[1]] = w
+                    w = wp
                 prec = H.PRECISIONS[precision]
                 self.conv[base] = PackedConv(w, params[base + ".bias"], prec, st)
                 # f16x3 / f16: the big 3x3x3 layers also get the Winograd-along-depth form (1.5x
@@ -184,8 +202,8 @@ class UNetEngine:
         h = (N + 1) // 2
         for a, b in ((0, h), (h, N)):
             rows = film_rows if film_stride == 0 else film_rows.reshape(-1)[a * film_stride:]
-            part = self.forward(x[a:b].contiguous(), low_res[a:b].contiguous(), rows, film_stride,
-                                None if res is None else res[a:b])
+            part = self.forward(x[a:b].contiguous(), None if low_res is None else low_res[a:b].contiguous(),
+                                rows, film_stride, None if res is None else res[a:b])
             if res is None:
                 res = torch.empty((N,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
                 res[a:b] = part
@@ -243,11 +261,23 @@ class _Plan:
         cin_conv = eng.conv[first.prefix]
         self.first_desc = None
         h = new_act(cin_conv.Cout, D, Hh, W)
-        # range of the two input volumes (they carry no statistics): [N][2] = max |x|, max |low_res|
-        self.in_absmax = torch.empty(N * 2, dtype=torch.float32, device=dev)
-        self.absmax_args = [0, 0, N, D * Hh * W, H.ptr(self.in_absmax), 0]
-        self.steps.append((lib.ddpm3d_absmax, self.absmax_args))
-        self.first_desc = self.conv_step(cin_conv, srcs=None, out=h, planar=True, bound=(self.in_absmax, 0, 2, 1))
+        if eng.planar:
+            # range of the two input volumes (they carry no statistics): [N][2] = max |x|, max |low_res|
+            self.in_absmax = torch.empty(N * 2, dtype=torch.float32, device=dev)
+            self.absmax_args = [0, 0, N, D * Hh * W, H.ptr(self.in_absmax), 0]
+            self.steps.append((lib.ddpm3d_absmax, self.absmax_args))
+            self.first_desc = self.conv_step(cin_conv, srcs=None, out=h, planar=True,
+                                             bound=(self.in_absmax, 0, 2, 1))
+        else:
+            # ordinary multi-channel input: (N, C, voxels) -> NDHWC padded to 16 channels, its range
+            ci = eng.in_channels
+            xin = new_act(eng.cin_pad, D, Hh, W, fp32=True)
+            self.in_absmax = torch.empty(N, dtype=torch.float32, device=dev)
+            self.absmax_args = [0, 0, N, ci * D * Hh * W, H.ptr(self.in_absmax), 0]
+            self.pad_args = [0, N, ci, D * Hh * W, eng.cin_pad, H.ptr(xin.buf), 0]
+            self.steps.append((lib.ddpm3d_absmax, self.absmax_args))
+            self.steps.append((lib.ddpm3d_ncdhw_to_ndhwc_pad, self.pad_args))
+            self.first_desc = self.conv_step(cin_conv, srcs=[xin], out=h, bound=(self.in_absmax, 0, 1, 1))
         hs = [h]
         for blk in topo.input[1:]:
             for i, e in enumerate(blk):
@@ -496,11 +526,14 @@ class _Plan:
     # ---- execution -----------------------------------------------------------
     def run(self, x, low_res, film_rows, film_stride, out=None):
         H.require_device(x, "x")
-        H.require_device(low_res, "low_res")
         st = H.stream()
-        self.first_desc.src0 = x.data_ptr()
-        self.first_desc.src1 = low_res.data_ptr()
-        self.absmax_args[0], self.absmax_args[1] = x.data_ptr(), low_res.data_ptr()
+        if self.eng.planar:
+            H.require_device(low_res, "low_res")
+            self.first_desc.src0 = x.data_ptr()
+            self.first_desc.src1 = low_res.data_ptr()
+            self.absmax_args[0], self.absmax_args[1] = x.data_ptr(), low_res.data_ptr()
+        else:
+            self.absmax_args[0] = self.pad_args[0] = x.data_ptr()
         fptr = film_rows.data_ptr()
         for a in self.film_patches:
             a[12], a[13] = fptr, film_stride

@@ -157,7 +157,9 @@ class GaussianDiffusion:
         flags = self._flags(clip_denoised)
         C = x.shape[1]
         want = 2 * C if flags & H.F_LEARN_SIGMA else C
-        assert C == 1 and tuple(model_output.shape) == (N, want, *x.shape[2:]), \
+        # th.split(model_output, C, dim=1) (gaussian_diffusion.py:264) of a contiguous (N, 2C, ...)
+        # tensor = two contiguous halves per sample: the kernel's (N, 2, C * voxels) view
+        assert tuple(model_output.shape) == (N, want, *x.shape[2:]), \
             "model output shape %s for input %s" % (tuple(model_output.shape), tuple(x.shape))
         H.require_device(x, "x")
         H.require_device(model_output, "model_output")
@@ -222,7 +224,7 @@ class GaussianDiffusion:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
         model_kwargs = model_kwargs or {}
-        fast = hasattr(model, "engine") and set(model_kwargs) == {"low_res"}
+        fast = hasattr(model, "engine") and set(model_kwargs) == {"low_res"} and len(shape) == 5
         # grad mode and the current device are changed around the COMPUTE of a step only and are
         # back to the caller's before every yield (the reference wraps p_sample alone in no_grad and
         # yields outside it, gaussian_diffusion.py:524-535): an abandoned *_progressive generator

@@ -104,9 +104,8 @@ def create_model_and_diffusion(image_size, class_cond, learn_sigma, num_channels
                                timestep_respacing, use_kl, predict_xstart, rescale_timesteps,
                                rescale_learned_sigmas, use_checkpoint, use_scale_shift_norm, resblock_updown,
                                use_fp16, use_new_attention_order):
-    """script_util.py:74-127.  The reference's create_model builds the 2-D RGB
-    UNetModel; this package implements the 3-D path only, so the model
-    constructor raises NotImplementedError (dims=2) -- the diffusion half works."""
+    """script_util.py:74-127: the 2-D RGB UNetModel (dims=2) + its diffusion.  The 2-D convs run as
+    depth-1 3-D convs on the same engine (engine.py)."""
     kw = dict(locals())
     model = create_model(image_size, num_channels, num_res_blocks, channel_mult=channel_mult,
                          learn_sigma=learn_sigma, class_cond=class_cond, use_checkpoint=use_checkpoint,

@@ -108,19 +108,24 @@ def _zero(m):
     return m
 
 
+def _conv(dims, cin, cout, k, **kw):
+    """nn.py:22-32 conv_nd: parameter container of a 2-D or 3-D convolution"""
+    return (nn.Conv2d if dims == 2 else nn.Conv3d)(cin, cout, k, **kw)
+
+
 class ResBlock(nn.Module):
     """Parameters of one residual block (unet.py:143-256)."""
 
-    def __init__(self, channels, emb_channels, out_channels, use_scale_shift_norm):
+    def __init__(self, channels, emb_channels, out_channels, use_scale_shift_norm, dims=3):
         super().__init__()
         self.in_layers = nn.Sequential(GroupNorm32(32, channels), nn.SiLU(),
-                                       nn.Conv3d(channels, out_channels, 3, padding=1))
+                                       _conv(dims, channels, out_channels, 3, padding=1))
         self.emb_layers = nn.Sequential(
             nn.SiLU(), nn.Linear(emb_channels, 2 * out_channels if use_scale_shift_norm else out_channels))
         self.out_layers = nn.Sequential(GroupNorm32(32, out_channels), nn.SiLU(), nn.Dropout(p=0.0),
-                                        _zero(nn.Conv3d(out_channels, out_channels, 3, padding=1)))
+                                        _zero(_conv(dims, out_channels, out_channels, 3, padding=1)))
         self.skip_connection = (nn.Identity() if out_channels == channels
-                                else nn.Conv3d(channels, out_channels, 1))
+                                else _conv(dims, channels, out_channels, 1))
 
 
 class AttentionBlock(nn.Module):
@@ -134,32 +139,32 @@ class AttentionBlock(nn.Module):
 
 
 class Downsample(nn.Module):
-    def __init__(self, channels):
+    def __init__(self, channels, dims=3):
         super().__init__()
-        self.op = nn.Conv3d(channels, channels, 3, stride=(1, 2, 2), padding=1)
+        self.op = _conv(dims, channels, channels, 3, stride=(2 if dims == 2 else (1, 2, 2)), padding=1)
 
 
 class Upsample(nn.Module):
-    def __init__(self, channels):
+    def __init__(self, channels, dims=3):
         super().__init__()
-        self.conv = nn.Conv3d(channels, channels, 3, padding=1)
+        self.conv = _conv(dims, channels, channels, 3, padding=1)
 
 
 class _Block(nn.Sequential):
     """A TimestepEmbedSequential-shaped holder (indices are state_dict key parts)."""
 
 
-def _container(layer, ted, film):
+def _container(layer, ted, film, dims=3):
     if layer.kind == "conv":
-        return nn.Conv3d(layer.cin, layer.cout, 3, padding=1)
+        return _conv(dims, layer.cin, layer.cout, 3, padding=1)
     if layer.kind == "res":
-        return ResBlock(layer.cin, ted, layer.cout, film)
+        return ResBlock(layer.cin, ted, layer.cout, film, dims)
     if layer.kind == "attn":
         return AttentionBlock(layer.cin)
     if layer.kind == "downconv":
-        return Downsample(layer.cin)
+        return Downsample(layer.cin, dims)
     if layer.kind == "upconv":
-        return Upsample(layer.cin)
+        return Upsample(layer.cin, dims)
     raise ValueError(layer.kind)
 
 
@@ -175,8 +180,8 @@ class UNetModel_noatt(nn.Module):
                  num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
                  use_new_attention_order=False):
         super().__init__()
-        if dims != 3:
-            raise NotImplementedError("the HIP engine implements the 3-D model (dims=3) only")
+        if dims not in (2, 3):
+            raise NotImplementedError("the HIP engine implements the 2-D and 3-D models (dims 2 or 3)")
         if num_classes is not None:
             raise NotImplementedError("class conditioning is unused by the 3-D PET model")
         # dropout: nn.Dropout is the identity in eval mode (unet.py:209), and this package only
@@ -214,12 +219,12 @@ class UNetModel_noatt(nn.Module):
         t = self.topology
         self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
         self.input_blocks = nn.ModuleList(
-            [_Block(*[_container(l, ted, use_scale_shift_norm) for l in blk]) for blk in t.input])
-        self.middle_block = _Block(*[_container(l, ted, use_scale_shift_norm) for l in t.middle])
+            [_Block(*[_container(l, ted, use_scale_shift_norm, dims) for l in blk]) for blk in t.input])
+        self.middle_block = _Block(*[_container(l, ted, use_scale_shift_norm, dims) for l in t.middle])
         self.output_blocks = nn.ModuleList(
-            [_Block(*[_container(l, ted, use_scale_shift_norm) for l in blk]) for blk in t.output])
+            [_Block(*[_container(l, ted, use_scale_shift_norm, dims) for l in blk]) for blk in t.output])
         self.out = nn.Sequential(GroupNorm32(32, t.final_ch), nn.SiLU(),
-                                 _zero(nn.Conv3d(t.input_ch, out_channels, 3, padding=1)))
+                                 _zero(_conv(dims, t.input_ch, out_channels, 3, padding=1)))
         self._engine = None
         self._engine_key = None
         # arithmetic of the 3x3x3 convolutions' products: "f16x3" (default: each fp32
@@ -263,21 +268,36 @@ class UNetModel_noatt(nn.Module):
             params = {k: v.detach().float().contiguous() for k, v in self.state_dict().items()}
             with torch.cuda.device(p0.device):
                 self._engine = UNetEngine(self.topology, params, self.model_channels,
-                                          self.use_scale_shift_norm, p0.device, self.conv_precision)
+                                          self.use_scale_shift_norm, p0.device, self.conv_precision,
+                                          in_channels=self.in_channels, planar=self.PLANAR_INPUT,
+                                          winograd=self.dims == 3)
             self._engine_key = key
         return self._engine
 
+    PLANAR_INPUT = False   # SuperRes models: the first conv reads x and low_res as two planes
+
     def forward(self, x, timesteps, y=None, low_res=None):
-        """x: (N, in_channels_x, D, H, W) with low_res supplying the second channel."""
+        """unet.py:687-716 / :1015-1044.  x: (N, in_channels, [D,] H, W).  The SuperRes subclasses
+        pass low_res, which supplies the second input channel (unet.py:1687-1694)."""
         assert y is None, "must specify y if and only if the model is class-conditional"
-        if low_res is None:
-            raise RuntimeError("the 3-D model is conditional: pass low_res=... (unet.py:1687)")
+        if self.PLANAR_INPUT and low_res is None:
+            raise RuntimeError("the super-resolution model is conditional: pass low_res=... (unet.py:1687)")
+        if not self.PLANAR_INPUT and low_res is not None:
+            raise RuntimeError("low_res is an argument of the SuperRes models only")
         H.require_device(x, "x")
         eng = self.engine()
+        flat = x.dim() == 4                       # dims=2: (N, C, H, W) runs as depth-1 volumes
+        if flat != (self.dims == 2):
+            raise RuntimeError("a dims=%d model takes %d-D tensors" % (self.dims, self.dims + 2))
         with torch.cuda.device(x.device):
             rows = eng.film_rows(timesteps.to(device=x.device, dtype=torch.float32).contiguous())
-            out = eng.forward(x, low_res.to(x.device).contiguous(), rows, eng.film_total)
-            return out.clone()
+            xv = x.unsqueeze(2) if flat else x
+            lr = None
+            if low_res is not None:
+                lr = low_res.to(x.device).contiguous()
+                lr = lr.unsqueeze(2) if flat else lr
+            out = eng.forward(xv, lr, rows, eng.film_total).clone()
+            return out.squeeze(2) if flat else out
 
 
 class UNetModel(UNetModel_noatt):
@@ -289,6 +309,7 @@ class UNetModel(UNetModel_noatt):
 class SuperResModel_noatt(UNetModel_noatt):
     """unet.py:1676-1694: conditions on `low_res` by channel concatenation (the
     concat itself is virtual: the first conv reads the two volumes directly)."""
+    PLANAR_INPUT = True
 
     def __init__(self, image_size, in_channels, *args, **kwargs):
         super().__init__(image_size, int(in_channels * 2), *args, **kwargs)
@@ -299,6 +320,7 @@ class SuperResModel_noatt(UNetModel_noatt):
 
 class SuperResModel(UNetModel):
     """unet.py:1655-1673."""
+    PLANAR_INPUT = True
 
     def __init__(self, image_size, in_channels, *args, **kwargs):
         super().__init__(image_size, int(in_channels * 2), *args, **kwargs)

@@ -269,6 +269,10 @@ int ddpm3d_attention_p(const float* qkv, int N, int T, int heads, int head_chann
 /* layout changes at the API edge */
 int ddpm3d_ncdhw_to_ndhwc(const float* in, int N, int C, int voxels, float* out, void* stream);
 int ddpm3d_ndhwc_to_ncdhw(const float* in, int N, int C, int voxels, float* out, void* stream);
+/* (N, C, voxels) -> (N, voxels, Cpad) with channels [C, Cpad) zero: the network input of the models
+ * whose first conv reads an ordinary multi-channel tensor (create_model's RGB UNetModel,
+ * script_util.py:130-184), padded to the convs' 16-channel granularity. */
+int ddpm3d_ncdhw_to_ndhwc_pad(const float* in, int N, int C, int voxels, int Cpad, float* out, void* stream);
 
 /* out[n][z][y][x][:] = in[n][z][2y][2x][:] on NDHWC tensors (even H, W; C % 4 == 0).
  * Downsample(use_conv=True) (unet.py:129-133, `resblock_updown=False`): a 3x3x3 conv with

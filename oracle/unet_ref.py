@@ -7,7 +7,9 @@ unet.py:1015-1044 (forward), unet.py:236-256 (ResBlock), unet.py:102-105 /
 :129-136 (H,W-only up/down-sampling for dims=3), unet.py:296-305 + :337-354
 (AttentionBlock with the legacy head layout), nn.py:93-121 (GroupNorm32,
 timestep_embedding), unet.py:1687-1694 (SuperRes concat of low_res) and
-script_util.py:334-450 (flag -> architecture mapping).
+script_util.py:334-450 (flag -> architecture mapping).  cfg["dims"] = 2 gives
+the 2-D network of create_model (script_util.py:130-184: UNetModel, dims=2,
+RGB in, mid-block attention): same topology, Conv2d / 2x2 pooling.
 """
 
 import math
@@ -43,6 +45,24 @@ def sr_config(large_size=256, num_channels=128, num_res_blocks=2, learn_sigma=Fa
         resblock_updown=resblock_updown,
         mid_attention=mid_attention,  # False = UNetModel_noatt, True = UNetModel
     )
+
+
+def model2d_config(image_size=64, num_channels=128, num_res_blocks=2, channel_mult="", learn_sigma=False,
+                   attention_resolutions="16", num_heads=1, num_head_channels=-1, num_heads_upsample=-1,
+                   use_scale_shift_norm=False, resblock_updown=False, **_ignored):
+    """script_util.py:130-184 (create_model): the 2-D RGB UNetModel."""
+    if channel_mult == "":
+        mult = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4),
+                64: (1, 2, 3, 4)}[image_size]
+    else:
+        mult = tuple(int(m) for m in channel_mult.split(","))
+    return dict(
+        dims=2, in_channels=3, model_channels=num_channels, out_channels=6 if learn_sigma else 3,
+        num_res_blocks=num_res_blocks,
+        attention_ds=tuple(image_size // int(r) for r in attention_resolutions.split(",")),
+        channel_mult=mult, num_heads=num_heads, num_head_channels=num_head_channels,
+        num_heads_upsample=num_heads if num_heads_upsample == -1 else num_heads_upsample,
+        use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown, mid_attention=True)
 
 
 # --------------------------------------------------------------------------
@@ -123,22 +143,24 @@ def param_shapes(cfg):
     res = [("time_embed.0.weight", (ted, mc)), ("time_embed.0.bias", (ted,)),
            ("time_embed.2.weight", (ted, ted)), ("time_embed.2.bias", (ted,))]
     topo = topology(cfg)
+    k3 = (3,) * cfg.get("dims", 3)
+    k1 = (1,) * cfg.get("dims", 3)
 
     def layer(entry):
         p, kind = entry[0], entry[1]
         if kind == "conv":
             _, _, ci, co = entry
-            return [(p + ".weight", (co, ci, 3, 3, 3)), (p + ".bias", (co,))]
+            return [(p + ".weight", (co, ci) + k3), (p + ".bias", (co,))]
         if kind == "res":
             _, _, ci, co, _ud = entry
             e = 2 * co if cfg["use_scale_shift_norm"] else co
             r = [(p + ".in_layers.0.weight", (ci,)), (p + ".in_layers.0.bias", (ci,)),
-                 (p + ".in_layers.2.weight", (co, ci, 3, 3, 3)), (p + ".in_layers.2.bias", (co,)),
+                 (p + ".in_layers.2.weight", (co, ci) + k3), (p + ".in_layers.2.bias", (co,)),
                  (p + ".emb_layers.1.weight", (e, ted)), (p + ".emb_layers.1.bias", (e,)),
                  (p + ".out_layers.0.weight", (co,)), (p + ".out_layers.0.bias", (co,)),
-                 (p + ".out_layers.3.weight", (co, co, 3, 3, 3)), (p + ".out_layers.3.bias", (co,))]
+                 (p + ".out_layers.3.weight", (co, co) + k3), (p + ".out_layers.3.bias", (co,))]
             if ci != co:
-                r += [(p + ".skip_connection.weight", (co, ci, 1, 1, 1)),
+                r += [(p + ".skip_connection.weight", (co, ci) + k1),
                       (p + ".skip_connection.bias", (co,))]
             return r
         if kind == "attn":
@@ -148,10 +170,10 @@ def param_shapes(cfg):
                     (p + ".proj_out.weight", (c, c, 1)), (p + ".proj_out.bias", (c,))]
         if kind == "downconv":
             c = entry[2]
-            return [(p + ".op.weight", (c, c, 3, 3, 3)), (p + ".op.bias", (c,))]
+            return [(p + ".op.weight", (c, c) + k3), (p + ".op.bias", (c,))]
         if kind == "upconv":
             c = entry[2]
-            return [(p + ".conv.weight", (c, c, 3, 3, 3)), (p + ".conv.bias", (c,))]
+            return [(p + ".conv.weight", (c, c) + k3), (p + ".conv.bias", (c,))]
         raise ValueError(kind)
 
     for blk in topo["input"]:
@@ -163,7 +185,7 @@ def param_shapes(cfg):
         for e in blk:
             res += layer(e)
     res += [("out.0.weight", (topo["final_ch"],)), ("out.0.bias", (topo["final_ch"],)),
-            ("out.2.weight", (cfg["out_channels"], topo["input_ch"], 3, 3, 3)),
+            ("out.2.weight", (cfg["out_channels"], topo["input_ch"]) + k3),
             ("out.2.bias", (cfg["out_channels"],))]
     return res
 
@@ -187,13 +209,22 @@ def gn32(sd, p, x):
     return F.group_norm(x.float(), 32, sd[p + ".weight"], sd[p + ".bias"], 1e-5).type(x.dtype)
 
 
+def conv(x, w, b, **kw):
+    # nn.py:28-38 conv_nd
+    return (F.conv3d if x.dim() == 5 else F.conv2d)(x, w, b, **kw)
+
+
 def pool_hw(x):
-    # unet.py:129-136: AvgPool3d kernel=stride=(1,2,2)
+    # unet.py:129-136: AvgPool3d kernel=stride=(1,2,2); dims=2: 2x2
+    if x.dim() == 4:
+        return F.avg_pool2d(x, 2, 2)
     return F.avg_pool3d(x, (1, 2, 2), (1, 2, 2))
 
 
 def up_hw(x):
-    # unet.py:102-105: nearest to (D, 2H, 2W)
+    # unet.py:102-105: nearest to (D, 2H, 2W); dims=2: scale_factor 2
+    if x.dim() == 4:
+        return F.interpolate(x, scale_factor=2, mode="nearest")
     return F.interpolate(x, (x.shape[2], x.shape[3] * 2, x.shape[4] * 2), mode="nearest")
 
 
@@ -204,18 +235,18 @@ def resblock(sd, p, x, emb, updown, film):
         h, x = pool_hw(h), pool_hw(x)
     elif updown == "up":
         h, x = up_hw(h), up_hw(x)
-    h = F.conv3d(h, sd[p + ".in_layers.2.weight"], sd[p + ".in_layers.2.bias"], padding=1)
+    h = conv(h, sd[p + ".in_layers.2.weight"], sd[p + ".in_layers.2.bias"], padding=1)
     e = F.linear(F.silu(emb), sd[p + ".emb_layers.1.weight"], sd[p + ".emb_layers.1.bias"])
-    e = e[:, :, None, None, None]
+    e = e[(..., ) + (None,) * (x.dim() - 2)]
     if film:
         scale, shift = torch.chunk(e, 2, dim=1)
         h = gn32(sd, p + ".out_layers.0", h) * (1 + scale) + shift
         h = F.silu(h)
     else:
         h = F.silu(gn32(sd, p + ".out_layers.0", h + e))
-    h = F.conv3d(h, sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
+    h = conv(h, sd[p + ".out_layers.3.weight"], sd[p + ".out_layers.3.bias"], padding=1)
     if (p + ".skip_connection.weight") in sd:
-        x = F.conv3d(x, sd[p + ".skip_connection.weight"], sd[p + ".skip_connection.bias"])
+        x = conv(x, sd[p + ".skip_connection.weight"], sd[p + ".skip_connection.bias"])
     return x + h
 
 
@@ -239,15 +270,16 @@ def attention(sd, p, x, n_heads):
 def run_layer(sd, cfg, entry, h, emb):
     p, kind = entry[0], entry[1]
     if kind == "conv":
-        return F.conv3d(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
+        return conv(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
     if kind == "res":
         return resblock(sd, p, h, emb, entry[4], cfg["use_scale_shift_norm"])
     if kind == "attn":
         return attention(sd, p, h, entry[3])
     if kind == "downconv":
-        return F.conv3d(h, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=(1, 2, 2), padding=1)
+        return conv(h, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=(1, 2, 2) if h.dim() == 5 else 2,
+                    padding=1)
     if kind == "upconv":
-        return F.conv3d(up_hw(h), sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=1)
+        return conv(up_hw(h), sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=1)
     raise ValueError(kind)
 
 
@@ -281,4 +313,4 @@ def unet_forward(sd, cfg, x, timesteps, low_res=None, taps=None):
         if taps is not None:
             taps["output_blocks.%d" % k] = h
     h = F.silu(gn32(sd, "out.0", h))
-    return F.conv3d(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)
+    return conv(h, sd["out.2.weight"], sd["out.2.bias"], padding=1)

@@ -283,8 +283,48 @@ def gen_script_helpers():
     save("script_helpers.npz", **out)
 
 
+def model2d_flags(**over):
+    """create_model_and_diffusion's flag set (script_util.py:41-66) at a CPU-sized 2-D RGB network:
+    attention at ds 4 and in the middle block, conv down/upsampling (resblock_updown False)."""
+    d = ref_su.model_and_diffusion_defaults()
+    d.update(image_size=64, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", num_head_channels=32,
+             attention_resolutions="16", learn_sigma=True, use_scale_shift_norm=True,
+             timestep_respacing="6")
+    d.update(over)
+    return d
+
+
+def gen_model2d():
+    """The reference's 2-D path (create_model_and_diffusion, script_util.py:74-184: UNetModel with
+    dims=2, 3 input channels, 3 or 6 output channels): state_dict layout, one forward, a 6-step
+    p_sample_loop and a 6-step DDIM loop.  Tensors are (N, 3, H, W)."""
+    out = {}
+    variants = {
+        "film": {},
+        "updown_additive": dict(resblock_updown=True, use_scale_shift_norm=False, learn_sigma=False),
+    }
+    keys = {}
+    for tag, over in variants.items():
+        fl = model2d_flags(**over)
+        model, diff = ref_su.create_model_and_diffusion(**fl)
+        keys[tag] = load_synth(model, seed=2)
+        shape = (2, 3, 32, 48)
+        x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0])
+        with torch.no_grad():
+            out[tag + "/forward"] = model(x, torch.tensor([617, 3])).numpy()
+        T = diff.num_timesteps
+        draws = synth.synth_noise(shape, T + 1, seed=10)
+        for kind in ("ddpm", "ddim"):
+            with _InjectNoise(draws[1:]), torch.no_grad():
+                loop = diff.p_sample_loop if kind == "ddpm" else diff.ddim_sample_loop
+                out["%s/%s" % (tag, kind)] = loop(model, shape, noise=torch.from_numpy(draws[0])).numpy()
+    with open(os.path.join(HERE, "model2d_keys.json"), "w") as f:
+        json.dump(keys, f)
+    save("model2d.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "temb", "keys", "resblocks", "unet", "sampler", "helpers"]
+    which = sys.argv[1:] or ["schedules", "temb", "keys", "resblocks", "unet", "sampler", "helpers", "model2d"]
     if "schedules" in which:
         gen_schedules()
     if "temb" in which:
@@ -297,6 +337,8 @@ if __name__ == "__main__":
         gen_unet_forward()
     if "sampler" in which:
         gen_sampler()
+    if "model2d" in which:
+        gen_model2d()
     if "helpers" in which:
         gen_script_helpers()
     if "sampler250" in which:       # ~10 CPU-minutes; not part of the default list

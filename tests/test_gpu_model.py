@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import rel_err, rel_err_per_channel
 from guided_diffusion import script_util as su
 from guided_diffusion import synth
 
@@ -277,3 +277,43 @@ def test_cpu_tensors_are_refused():
     x, lr = inputs((1, 1, 4, 16, 16))
     with pytest.raises(RuntimeError, match="GPU"):
         model(x, torch.tensor([1]), low_res=lr)
+
+
+# ---------------------------------------------------------------- the 2-D network (create_model)
+MODEL2D_VARIANTS = {
+    "film": {},
+    "updown_additive": dict(resblock_updown=True, use_scale_shift_norm=False, learn_sigma=False),
+}
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("tag", sorted(MODEL2D_VARIANTS))
+def test_model2d_forward_and_loops_vs_reference_golden(golden, tag, precision):
+    """create_model_and_diffusion (script_util.py:74-184): the 2-D RGB UNetModel (dims=2, 3 channels
+    in, 3 or 6 out, attention at ds 4 and in the middle block, strided-conv or ResBlock resampling)
+    on the HIP engine -- (N, 3, H, W) images run as depth-1 volumes -- against the reference's own
+    forward and 6-step DDPM / DDIM loops (tests/golden/model2d.npz)."""
+    fl = su.model_and_diffusion_defaults()
+    fl.update(image_size=64, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", num_head_channels=32,
+              attention_resolutions="16", learn_sigma=True, use_scale_shift_norm=True, timestep_respacing="6")
+    fl.update(MODEL2D_VARIANTS[tag])
+    model, diff = su.create_model_and_diffusion(**fl)
+    model.conv_precision = precision
+    model.load_state_dict({k: torch.from_numpy(synth.synth_param(k, tuple(v.shape), 2))
+                           for k, v in model.state_dict().items()})
+    model.to("cuda").eval()
+    g = golden("model2d.npz")
+    shape = (2, 3, 32, 48)
+    x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0]).cuda()
+    with torch.no_grad():
+        y = model(x, torch.tensor([617, 3]).cuda())
+    assert tuple(y.shape) == g[tag + "/forward"].shape
+    assert rel_err_per_channel(y.cpu().numpy(), g[tag + "/forward"]) < 2e-5
+    draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, 7, seed=10)]
+    a = diff.p_sample_loop(model, shape, draws[0], step_noise=draws[1:])
+    b = diff.ddim_sample_loop(model, shape, draws[0], step_noise=draws[1:])
+    ea, eb = rel_err(a.cpu().numpy(), g[tag + "/ddpm"]), rel_err(b.cpu().numpy(), g[tag + "/ddim"])
+    print("2-D %s %s: ddpm %.2e ddim %.2e" % (tag, precision, ea, eb))
+    assert ea < 1e-3 and eb < 1e-3              # the north_star bar, as for the 3-D loops above
+    with pytest.raises(RuntimeError):
+        model(x.unsqueeze(2), torch.tensor([617, 3]).cuda())      # a dims=2 model takes 4-D tensors

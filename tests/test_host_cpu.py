@@ -182,9 +182,29 @@ def test_no_cpu_path():
 def test_unsupported_features_fail_loudly():
     from guided_diffusion.unet import UNetModel_noatt
     with pytest.raises(NotImplementedError):
-        su.create_model(64, 32, 1)      # the 2-D RGB model of create_model_and_diffusion
+        UNetModel_noatt(32, 2, 32, 2, 1, (), dims=1)
     with pytest.raises(NotImplementedError):
         UNetModel_noatt(32, 2, 32, 2, 1, (), dims=3, num_classes=10)
     d = su.create_gaussian_diffusion()
     with pytest.raises(NotImplementedError):
         next(d.p_sample_loop_progressive(None, (1, 1, 2, 2, 2), cond_fn=lambda *a: 0))
+
+
+def test_model2d_state_dict_layout_matches_reference():
+    """create_model_and_diffusion (script_util.py:74-184): the 2-D RGB UNetModel's state_dict keys
+    and shapes, in registration order, equal the reference's (tests/golden/model2d_keys.json)."""
+    import json
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "model2d_keys.json")) as f:
+        ref = json.load(f)
+    fl = su.model_and_diffusion_defaults()
+    fl.update(image_size=64, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", num_head_channels=32,
+              attention_resolutions="16", learn_sigma=True, use_scale_shift_norm=True, timestep_respacing="6")
+    variants = {"film": {}, "updown_additive": dict(resblock_updown=True, use_scale_shift_norm=False,
+                                                    learn_sigma=False)}
+    for tag, over in variants.items():
+        model, diff = su.create_model_and_diffusion(**dict(fl, **over))
+        assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == ref[tag], tag
+        assert diff.num_timesteps == 6 and model.dims == 2
+        with pytest.raises(RuntimeError):          # no CPU path
+            model(torch.zeros(1, 3, 32, 32), torch.zeros(1))

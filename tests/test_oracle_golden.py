@@ -185,3 +185,43 @@ def test_published_250_step_chain_head(golden):
             img = mean + torch.exp(0.5 * log_var) * draws[k + 1]
             rows.append((float(img.mean()), float(x0.mean()), float(img.std())))
     assert np.allclose(np.array(rows), g["trace"][:steps], rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------- the 2-D network (create_model)
+MODEL2D = dict(image_size=64, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", num_head_channels=32,
+               attention_resolutions="16", learn_sigma=True, use_scale_shift_norm=True)
+MODEL2D_VARIANTS = {
+    "film": {},
+    "updown_additive": dict(resblock_updown=True, use_scale_shift_norm=False, learn_sigma=False),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(MODEL2D_VARIANTS))
+def test_model2d_oracle_vs_reference(golden, tag):
+    """create_model_and_diffusion's 2-D RGB network (script_util.py:74-184) through the oracle:
+    state_dict layout, one forward, 6-step DDPM and DDIM loops on (2, 3, 32, 48) images -- against
+    the reference's outputs (tests/golden/model2d.npz, make_golden.py gen_model2d)."""
+    fl = dict(MODEL2D, **MODEL2D_VARIANTS[tag])
+    cfg = unet_ref.model2d_config(**fl)
+    with open(os.path.join(GOLDEN, "model2d_keys.json")) as f:
+        ref_keys = json.load(f)[tag]
+    assert [[k, list(s)] for k, s in unet_ref.param_shapes(cfg)] == ref_keys
+    sd = _sd(cfg, seed=2)
+    g = golden("model2d.npz")
+    shape = (2, 3, 32, 48)
+    x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0])
+    with torch.no_grad():
+        y = unet_ref.unet_forward(sd, cfg, x, torch.tensor([617, 3])).numpy()
+    assert rel_err(y, g[tag + "/forward"]) < 1e-6
+    tmap, tb = schedule_ref.spaced_schedule(1000, "linear", "6")
+    draws = [torch.from_numpy(a) for a in synth.synth_noise(shape, 7, seed=10)]
+
+    def model_fn(xx, t, _):
+        return unet_ref.unet_forward(sd, cfg, xx, t)
+
+    with torch.no_grad():
+        a = sampler_ref.p_sample_loop(model_fn, tmap, tb, draws[0], draws[1:], None, learn_sigma=fl["learn_sigma"])
+        b = sampler_ref.ddim_sample_loop(model_fn, tmap, tb, draws[0], draws[1:], None,
+                                         learn_sigma=fl["learn_sigma"])
+    assert rel_err(a.numpy(), g[tag + "/ddpm"]) < 1e-5
+    assert rel_err(b.numpy(), g[tag + "/ddim"]) < 1e-5
