@@ -284,11 +284,11 @@ __global__ __launch_bounds__(256, (PIPEM == 2 ? 1 : (TXL == 2 ? 2 : 3))) void co
     conv_epilogue<PREC, WM, MT, TXL, TYL>(p, acc, n, z0, y0, x0, tile_in_n, wm, cout, half, wg.split, asc.inv);
 }
 
-// This file is compiled once per arithmetic mode (-DDDPM3D_PREC_ONLY=0|1|2, see the
-// Makefile) so the instantiations build in parallel; the mode-independent parts below
-// (split-K reduction, dispatcher) live in the PREC 0 object only.
+// This file is compiled once per arithmetic mode (-DDDPM3D_PREC_ONLY=0|1|2|5, and 3 = the
+// Winograd-D kernels of every mode; see the Makefile) so the instantiations build in parallel; the
+// mode-independent parts below (split-K reduction, dispatcher) live in the PREC 0 object only.
 #ifndef DDPM3D_PREC_ONLY
-#error "compile with -DDDPM3D_PREC_ONLY=0, 1, 2 or 5"
+#error "compile with -DDDPM3D_PREC_ONLY=0, 1, 2, 3 or 5"
 #endif
 #if DDPM3D_PREC_ONLY == 0
 
@@ -441,12 +441,56 @@ hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) 
 }
 #endif  // DDPM3D_PREC_ONLY == 0
 
-#if DDPM3D_PREC_ONLY == 1
-// Winograd-D form of the f16x3 / f16 3x3x3 conv (eligibility is checked by the C ABI)
+#if DDPM3D_PREC_ONLY == 3
+// Winograd-D forms of the f16x3 / f16 / bf16 3x3x3 conv, an object of their own (conv3d_p3.o;
+// eligibility is checked by the C ABI)
 #include "conv3d_wz.h"
+#include "conv3d_wzp.h"
+
+template <int MODE, int DBG = 0>
+static hipError_t launch_wzp(const ConvK& k, int gx, int gy, hipStream_t st) {
+    constexpr int lds = 8 * 4096 * 4;   // the epilogue's plane exchange (the two images need 2 * WzGeom::BUF)
+    static_assert(lds >= 2 * WzGeom::BUF, "exchange area covers the images");
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wzp_kernel<MODE, DBG>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((conv3d_wzp_kernel<MODE, DBG>), dim3(gx, gy, 1), dim3(512), lds, st, k);
+    return hipGetLastError();
+}
+
 hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t st) {
-    const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     const int gy = k.CoutPad / 128;
+    // Plane-pair form (conv3d_wzp.h): 8x8x4 tiles, one 512-thread workgroup per CU.  Needs whole
+    // z-quads and enough tiles to give every CU one; the split-K levels stay on the form below.
+    {
+        const long long wgs = (long long)k.N * (k.D / 4) * k.tilesY * k.tilesX * gy;
+        const bool can = k.D % 4 == 0 && k.ksplit == 1;
+        const bool want = (k.hint & DDPM3D_HINT_WZ_PAIR_ON) ? true
+                          : (k.hint & DDPM3D_HINT_WZ_PAIR_OFF) ? false : wgs >= 224;
+        if (can && want) {
+            const int gxp = k.N * (k.D / 4) * k.tilesY * k.tilesX;
+            if (c.PREC == DDPM3D_PREC_F16_WZ) return launch_wzp<WZ_F16>(k, gxp, gy, st);
+            if (c.PREC == DDPM3D_PREC_BF16_WZ) return launch_wzp<WZ_BF16>(k, gxp, gy, st);
+#ifdef DDPM3D_WZP_DEBUG
+            switch ((k.hint >> 12) & 127) {
+                case 64 + 4: return launch_wzp<WZ_F16X3, 68>(k, gxp, gy, st);
+                case 64 + 49: return launch_wzp<WZ_F16X3, 113>(k, gxp, gy, st);
+                case 17: return launch_wzp<WZ_F16X3, 17>(k, gxp, gy, st);
+                case 33: return launch_wzp<WZ_F16X3, 33>(k, gxp, gy, st);
+                case 49: return launch_wzp<WZ_F16X3, 49>(k, gxp, gy, st);
+                case 8: return launch_wzp<WZ_F16X3, 8>(k, gxp, gy, st);
+                case 9: return launch_wzp<WZ_F16X3, 9>(k, gxp, gy, st);
+                case 12: return launch_wzp<WZ_F16X3, 12>(k, gxp, gy, st);
+                case 1: return launch_wzp<WZ_F16X3, 1>(k, gxp, gy, st);
+                case 2: return launch_wzp<WZ_F16X3, 2>(k, gxp, gy, st);
+                case 4: return launch_wzp<WZ_F16X3, 4>(k, gxp, gy, st);
+                case 5: return launch_wzp<WZ_F16X3, 5>(k, gxp, gy, st);
+            }
+#endif
+            return launch_wzp<WZ_F16X3>(k, gxp, gy, st);
+        }
+    }
+    const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     constexpr size_t lds = (size_t)WzGeom::BUF;
     // One kernel form.  Measured and dropped in r02 (profiles/r02_layer_ab_*.txt): a
     // wave-specialised persistent form (compute waves + loader waves, tile walk, epilogue hand-off
@@ -461,7 +505,7 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16X3>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     return hipGetLastError();
 }
-#endif
+#else   // the direct kernels of one arithmetic mode
 
 // ---------------------------------------------------------------- dispatch
 template <int PREC, int PIPE, int KS, int WN, int MT, int TXL, int TYL>
@@ -503,3 +547,4 @@ hipError_t DDPM3D_CAT(ddpm3d_launch_conv_p, DDPM3D_PREC_ONLY)(const ConvK& k, co
 #undef CASE
     return hipErrorInvalidValue;
 }
+#endif  // DDPM3D_PREC_ONLY != 3
