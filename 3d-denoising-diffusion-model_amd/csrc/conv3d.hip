@@ -445,62 +445,24 @@ hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) 
 // Winograd-D forms of the f16x3 / f16 / bf16 3x3x3 conv, an object of their own (conv3d_p3.o;
 // eligibility is checked by the C ABI)
 #include "conv3d_wz.h"
-#include "conv3d_wzp.h"
-
-template <int MODE, int DBG = 0>
-static hipError_t launch_wzp(const ConvK& k, int gx, int gy, hipStream_t st) {
-    constexpr int lds = 8 * 4096 * 4;   // the epilogue's plane exchange (the two images need 2 * WzGeom::BUF)
-    static_assert(lds >= 2 * WzGeom::BUF, "exchange area covers the images");
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_wzp_kernel<MODE, DBG>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((conv3d_wzp_kernel<MODE, DBG>), dim3(gx, gy, 1), dim3(512), lds, st, k);
-    return hipGetLastError();
-}
 
 hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t st) {
     const int gy = k.CoutPad / 128;
-    // Plane-pair form (conv3d_wzp.h): 8x8x4 tiles, one 512-thread workgroup per CU.  Needs whole
-    // z-quads and enough tiles to give every CU one; the split-K levels stay on the form below.
-    {
-        const long long wgs = (long long)k.N * (k.D / 4) * k.tilesY * k.tilesX * gy;
-        const bool can = k.D % 4 == 0 && k.ksplit == 1;
-        const bool want = (k.hint & DDPM3D_HINT_WZ_PAIR_ON) ? true
-                          : (k.hint & DDPM3D_HINT_WZ_PAIR_OFF) ? false : wgs >= 224;
-        if (can && want) {
-            const int gxp = k.N * (k.D / 4) * k.tilesY * k.tilesX;
-            if (c.PREC == DDPM3D_PREC_F16_WZ) return launch_wzp<WZ_F16>(k, gxp, gy, st);
-            if (c.PREC == DDPM3D_PREC_BF16_WZ) return launch_wzp<WZ_BF16>(k, gxp, gy, st);
-#ifdef DDPM3D_WZP_DEBUG
-            switch ((k.hint >> 12) & 127) {
-                case 64 + 4: return launch_wzp<WZ_F16X3, 68>(k, gxp, gy, st);
-                case 64 + 49: return launch_wzp<WZ_F16X3, 113>(k, gxp, gy, st);
-                case 17: return launch_wzp<WZ_F16X3, 17>(k, gxp, gy, st);
-                case 33: return launch_wzp<WZ_F16X3, 33>(k, gxp, gy, st);
-                case 49: return launch_wzp<WZ_F16X3, 49>(k, gxp, gy, st);
-                case 8: return launch_wzp<WZ_F16X3, 8>(k, gxp, gy, st);
-                case 9: return launch_wzp<WZ_F16X3, 9>(k, gxp, gy, st);
-                case 12: return launch_wzp<WZ_F16X3, 12>(k, gxp, gy, st);
-                case 1: return launch_wzp<WZ_F16X3, 1>(k, gxp, gy, st);
-                case 2: return launch_wzp<WZ_F16X3, 2>(k, gxp, gy, st);
-                case 4: return launch_wzp<WZ_F16X3, 4>(k, gxp, gy, st);
-                case 5: return launch_wzp<WZ_F16X3, 5>(k, gxp, gy, st);
-            }
-#endif
-            return launch_wzp<WZ_F16X3>(k, gxp, gy, st);
-        }
-    }
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
     constexpr size_t lds = (size_t)WzGeom::BUF;
-    // One kernel form.  Measured and dropped in r02 (profiles/r02_layer_ab_*.txt): a
-    // wave-specialised persistent form (compute waves + loader waves, tile walk, epilogue hand-off
-    // through LDS) and a 128-row wave tile with one wave per SIMD (plain, and with the staging
-    // interleaved into the tap loop) -- all 3-15 % behind this one once the staging was cut to ~400
-    // instructions per item (conv3d_stage.h).
+    // One kernel form.  Measured and dropped in r02 (profiles/r02_layer_ab_*.txt, r02_wzp_plane_pair_*.txt,
+    // DESIGN.md 3.1b): a wave-specialised persistent form (compute waves + loader waves, tile walk,
+    // epilogue hand-off through LDS); a 128-row wave tile with one wave per SIMD (plain, and with the
+    // staging interleaved into the tap loop); a plane-pair form (8x8x4 tiles, two anti-phase halves of
+    // two transformed planes each, half the L2 weight stream) -- 0-15 % behind this one or equal to it.
+    // f16x3: the issue order of a tap (interleaved / clumped prefetches) by shape, as measured
+    // (profiles/r02_layer_ab_wz_interleave.txt): interleaved except for the 384-cout layers.
     if (c.PREC == DDPM3D_PREC_F16_WZ)
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     else if (c.PREC == DDPM3D_PREC_BF16_WZ)
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_BF16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+    else if (k.CoutPad % 384 != 0)
+        hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 1>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     else
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16X3>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     return hipGetLastError();

@@ -31,9 +31,7 @@ struct LdsGeom {
 // the raw split-K slab.  C/D map of a 32x32 MFMA: col = lane&31 (cout),
 // row = (reg&3) + 8*(reg>>2) + 4*half.
 // inv_act = 1 / activation scale of this sample (split-f16 modes; 1 in the exact mode)
-// ZSTEP: depth distance between consecutive z-slices of the accumulator tile (2 in conv3d_wzp.h,
-// whose waves hold every other output plane)
-template <int PREC, int WM, int MT, int TXL, int TYL, int ZSTEP = 1>
+template <int PREC, int WM, int MT, int TXL, int TYL>
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc)[MT], int n, int z0, int y0,
                                               int x0, int tile_in_n, int wm, int cout, int half, int ksplit_idx,
                                               float inv_act) {
@@ -53,7 +51,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
     {
         constexpr int TZ = WM * MT * 32 / (TX * TY);
         const bool split = p.ksplit > 1;
-        const bool full = z0 + (TZ - 1) * ZSTEP + 1 <= p.D && y0 + TY <= p.H && x0 + TX <= p.W;
+        const bool full = z0 + TZ <= p.D && y0 + TY <= p.H && x0 + TX <= p.W;
         // residual of a split conv is the reduce kernel's business
         const int rm = split ? DDPM3D_RES_NONE : p.res_mode;
         // the residual tensor of the up / down ResBlocks is the block input at the other
@@ -105,7 +103,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
-                    const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = (m0 >> (TXL + TYL)) * ZSTEP;
+                    const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
                     soff[reg] = (unsigned)((tz * p.H + ty) * p.W + tx) * cstride;
                 }
                 float r[16];
@@ -113,14 +111,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
-                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = (m0 >> (TXL + TYL)) * ZSTEP;
+                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
                         r[reg] = rload((unsigned)((tz * p.H + ty) * p.W + tx) * rstride);
                     }
                 } else if (rm == DDPM3D_RES_UP) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
-                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = (m0 >> (TXL + TYL)) * ZSTEP;
+                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
                         r[reg] = rload((unsigned)((tz * rH + (ty >> 1)) * rW + (tx >> 1)) * rstride);
                     }
                 } else if (rm == DDPM3D_RES_POOL) {
@@ -128,7 +126,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
-                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = (m0 >> (TXL + TYL)) * ZSTEP;
+                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
                         const unsigned so = (unsigned)((tz * rH + 2 * ty) * rW + 2 * tx) * rstride;
                         const float r00 = rload(so), r01 = rload(so + rstride);
                         const float r10 = rload(so + rW * rstride), r11 = rload(so + (rW + 1) * rstride);
@@ -172,7 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
                 const int m = (wm * MT + t) * 32 + row;
-                const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = (m >> (TXL + TYL)) * ZSTEP;
+                const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
                 const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
                 if (cvalid && z < p.D && y < p.H && x < p.W)
                     slab[(((size_t)z * p.H + y) * p.W + x) * p.Cout + cout] =
@@ -189,7 +187,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
         for (int reg = 0; reg < 16; ++reg) {
             const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
             const int m = (wm * MT + t) * 32 + row;
-            const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = (m >> (TXL + TYL)) * ZSTEP;
+            const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
             const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
             const bool ok = cvalid && z < p.D && y < p.H && x < p.W;
             if (ok) {

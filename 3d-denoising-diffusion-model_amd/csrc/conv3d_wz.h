@@ -30,7 +30,9 @@
 // MODE WZ_F16X3: three f16 MFMAs per product on hi/lo-split operands (DDPM3D_PREC_F16X3_WZ);
 // WZ_F16: one MFMA on the hi halves of the same packed image and LDS layout (DDPM3D_PREC_F16_WZ);
 // WZ_BF16: one bf16 MFMA on bf16-rounded operands, no scaling (DDPM3D_PREC_BF16_WZ)
-template <int MODE>
+// IL: the next tap's LDS reads and weight loads are spread between this tap's MFMAs
+// (sched_group_barrier) instead of issued in front of them
+template <int MODE, int IL = 0>
 __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     constexpr bool X3 = MODE == WZ_F16X3;
     constexpr int CK = DDPM3D_CONV_CK, NT = 36;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
                 if (X3) bq[(tap + 2) % 3][L] = buffer_load16(wrsrc, wlane, woff + wpart);
                 bump();
             }
-            __builtin_amdgcn_sched_barrier(0);   // prefetches issue BEFORE this tap's MFMAs
+            if constexpr (!IL) __builtin_amdgcn_sched_barrier(0);   // prefetches issue BEFORE this tap's MFMAs
             // next chunk's raw loads: after the chunk's last weight loads (vmcnt retires in order)
             if (tap == NT - 3 && more) stage_issue(p, sl, raw, n, z0, chunk + 1);
             const int j = tap / 9;
@@ -151,6 +153,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 acc[j][t] = mfma16<MODE == WZ_BF16>(af[tap & 1][t][0], bhi, acc[j][t]);
+            if constexpr (IL) {
+#pragma unroll
+                for (int i = 0; i < (X3 ? 4 : 2); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < (X3 ? 2 : 1); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
         }
     }
 

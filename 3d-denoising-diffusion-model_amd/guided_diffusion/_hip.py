@@ -30,7 +30,6 @@ IO_SRC0_BF16, IO_SRC1_BF16, IO_OUT_BF16, IO_RES_BF16 = 1, 2, 4, 8
 ABI_VERSION = 9
 # ddpm3d_conv_desc.kernel_hint bits (launch orders of identical arithmetic; tests and A/B measurements)
 HINT_WSTAT_OFF, HINT_WSTAT_ON = 0x100, 0x200
-HINT_WZ_PAIR_OFF, HINT_WZ_PAIR_ON = 0x400, 0x800    # Winograd-D kernel form (conv3d_wz.h / conv3d_wzp.h)
 
 _fp = C.c_void_p
 

@@ -150,11 +150,7 @@ enum {
 /* ddpm3d_conv_desc.kernel_hint */
 enum {
     DDPM3D_HINT_WSTAT_OFF = 0x100,/* workgroup -> XCD order: tiles fastest (activation-stationary)   */
-    DDPM3D_HINT_WSTAT_ON = 0x200, /*   cout blocks / K splits fastest (weight-stationary)            */
-    /* Winograd-D precisions: which of the two bit-identical kernel forms runs (default: by shape) */
-    DDPM3D_HINT_WZ_PAIR_OFF = 0x400, /* 8x8x2 tiles, 256-thread workgroups (conv3d_wz.h)             */
-    DDPM3D_HINT_WZ_PAIR_ON = 0x800   /* 8x8x4 tiles, plane-pair halves (conv3d_wzp.h); D % 4 == 0,
-                                        unsplit shapes only -- ignored otherwise                    */
+    DDPM3D_HINT_WSTAT_ON = 0x200  /*   cout blocks / K splits fastest (weight-stationary)            */
 };
 
 int ddpm3d_abi_version(void);

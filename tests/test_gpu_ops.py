@@ -616,46 +616,3 @@ def test_conv3d_launch_orders_agree_bitwise(hc):
                 else:
                     assert np.array_equal(o, ref_o), (i, precision, hint)
                     assert np.array_equal(s_, ref_s), (i, precision, hint)
-
-
-@pytest.mark.parametrize("precision", [3, 4, 6])
-def test_winograd_plane_pair_form_is_bit_identical(hc, precision):
-    """The two kernel forms of the Winograd-D precisions -- conv3d_wz.h (8x8x2 tiles, each wave all four
-    transformed planes) and conv3d_wzp.h (8x8x4 tiles, two halves of two planes each, met in the
-    epilogue through LDS) -- order every accumulator's products and the output transform identically:
-    outputs bit for bit equal, forced either way through kernel_hint.  Statistics rows partition the
-    voxels differently (z-pairs vs every other plane), so only their totals are compared.
-    Shapes: plain / concat / upsampled input, residual modes, batch, ragged H and W (general epilogue),
-    D = 4 (both z-pairs touch the volume's faces), bf16 tensors."""
-    import guided_diffusion._hip as H
-    cases = [
-        # N, D, H, W, ci (tuple = concat), co, in_mode, res_mode
-        (1, 8, 16, 16, (64,), 128, H.IN_SAME, H.RES_SAME),
-        (2, 4, 8, 24, (32, 32), 256, H.IN_SAME, H.RES_NONE),
-        (1, 12, 16, 16, (48,), 128, H.IN_UP, H.RES_UP),
-        (1, 4, 9, 20, (16,), 128, H.IN_SAME, H.RES_SAME),
-        (1, 16, 8, 8, (128,), 128, H.IN_SAME, H.RES_POOL),
-    ]
-    for i, (N, D, Hh, W, cis, co, in_mode, res_mode) in enumerate(cases):
-        up = in_mode == H.IN_UP
-        hs, ws = (Hh // 2, W // 2) if up else (Hh, W)
-        srcs = [hc.to_ndhwc(rnd(N, c, D, hs, ws, seed=100 + 7 * i + j)).cuda() for j, c in enumerate(cis)]
-        ci = sum(cis)
-        w = rnd(co, ci, 3, 3, 3, seed=20 + i, scale=0.05).cuda()
-        b = rnd(co, seed=30 + i).cuda()
-        A = (1.0 + 0.1 * rnd(N, ci, seed=40 + i)).cuda()
-        B = (0.1 * rnd(N, ci, seed=50 + i)).cuda()
-        rshape = {H.RES_SAME: (Hh, W), H.RES_UP: (Hh // 2, W // 2), H.RES_POOL: (2 * Hh, 2 * W)}.get(res_mode)
-        res = hc.to_ndhwc(rnd(N, co, D, *rshape, seed=60 + i)).cuda() if rshape else None
-        bf = precision == 6
-        if bf:
-            srcs = [s.to(torch.bfloat16) for s in srcs]
-            res = None if res is None else res.to(torch.bfloat16)
-        outs = []
-        for hint in (H.HINT_WZ_PAIR_OFF, H.HINT_WZ_PAIR_ON):
-            out, stats, _ = hc.conv3d(srcs, w, b, (D, Hh, W), in_mode=in_mode, aff=(A, B), act=H.ACT_SILU, res=res,
-                                      res_mode=res_mode, precision=precision, hint=hint, out_bf16=bf)
-            assert torch.isfinite(out.float()).all()
-            outs.append((out.float().cpu().numpy(), stats.double().sum(dim=2).cpu().numpy()))
-        assert np.array_equal(outs[0][0], outs[1][0]), (i, precision)
-        assert np.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-4), (i, precision)

@@ -34,8 +34,6 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--only64", action="store_true", help="only the full-resolution layers")
-    ap.add_argument("--what", default="form", choices=["form", "order", "wzp_debug"],
-                    help="form: conv3d_wz.h vs conv3d_wzp.h; order: workgroup -> XCD orders")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model, _, _ = bench.build_model(bench.PUBLISHED, "250", dev)
@@ -50,17 +48,7 @@ def main():
         model(x, t, low_res=lr)                       # builds the plan, fills every buffer
     torch.cuda.synchronize()
     plan = model.engine().plan(B, S, S, S)
-    variants = {"order": [("default", 0), ("wstat_off", H.HINT_WSTAT_OFF), ("wstat_on", H.HINT_WSTAT_ON)],
-                "form": [("default", 0), ("wz", H.HINT_WZ_PAIR_OFF), ("wz_pair", H.HINT_WZ_PAIR_ON)],
-                # a library built with -DDDPM3D_WZP_DEBUG: pieces of the plane-pair form (results are wrong)
-                "wzp_debug": [("wz", H.HINT_WZ_PAIR_OFF), ("wz_pair", H.HINT_WZ_PAIR_ON),
-                              ("nostage", H.HINT_WZ_PAIR_ON | 0x1000), ("notaps", H.HINT_WZ_PAIR_ON | 0x2000),
-                              ("interleave", H.HINT_WZ_PAIR_ON | 0x4000),
-                              ("il_nostage", H.HINT_WZ_PAIR_ON | 0x5000), ("ring4", H.HINT_WZ_PAIR_ON | 0x8000),
-                              ("r4_nostage", H.HINT_WZ_PAIR_ON | 0x9000), ("r4_il", H.HINT_WZ_PAIR_ON | 0xc000),
-                              ("ns_noA", H.HINT_WZ_PAIR_ON | 0x11000), ("ns_noB", H.HINT_WZ_PAIR_ON | 0x21000),
-                              ("ns_noAB", H.HINT_WZ_PAIR_ON | 0x31000), ("il_noepi", H.HINT_WZ_PAIR_ON | 0x44000),
-                              ("noAB_noepi", H.HINT_WZ_PAIR_ON | 0x71000)]}[a.what]
+    variants = [("default", 0), ("wstat_off", H.HINT_WSTAT_OFF), ("wstat_on", H.HINT_WSTAT_ON)]
     seen = {}
     print("# published architecture, %dx1x%d^3, %s; ms per launch (median of %d rounds x %d launches)"
           % (B, S, a.precision, a.rounds, a.iters))
