@@ -175,6 +175,11 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         return fail(DDPM3D_EINVAL, "conv3d: statistics only with NDHWC output");
     const long long blocks = (long long)k.N * k.tilesZ * k.tilesY * k.tilesX;
     if (blocks > 0x7fffffffLL) return fail(DDPM3D_EINVAL, "conv3d: grid too large");
+    // one or two output channels (the network's last layer): its own kernel (conv3d_skinny.hip)
+    if (d->ksize == 3 && d->Cout <= 2 && d->in_mode == DDPM3D_IN_SAME && d->C1 == 0 && !d->stats &&
+        d->res_mode == DDPM3D_RES_NONE &&
+        ddpm3d_skinny_ok(k.CinPad, d->precision, (d->io_dtype & DDPM3D_IO_SRC0_BF16) != 0))
+        return launched(ddpm3d_launch_conv_skinny(k, d->precision, (hipStream_t)stream), "conv3d (skinny)");
     const int rc = launched(ddpm3d_launch_conv(k, c, (hipStream_t)stream), "conv3d");
     if (rc != DDPM3D_OK || c.S == 1) return rc;
     return launched(ddpm3d_launch_splitk_reduce(k, (hipStream_t)stream), "conv3d split-K reduce");

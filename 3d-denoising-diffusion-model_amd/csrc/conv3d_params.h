@@ -138,6 +138,8 @@ static inline size_t ddpm3d_packed_bytes(int Cout, int Cin, int ksize, int prec)
 
 hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st);
 hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st);
+hipError_t ddpm3d_launch_conv_skinny(const ConvK& k, int prec, hipStream_t st);   // conv3d_skinny.hip
+bool ddpm3d_skinny_ok(int CinPad, int prec, bool src_bf16);
 
 // Residual term of the conv epilogue for output element (n, z, y, x, cout);
 // shared by the conv kernel and the split-K reduce kernel.

@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_err
+from conftest import rel_err, rel_err_per_channel
 
 pytestmark = pytest.mark.gpu
 
@@ -616,3 +616,43 @@ def test_conv3d_launch_orders_agree_bitwise(hc):
                 else:
                     assert np.array_equal(o, ref_o), (i, precision, hint)
                     assert np.array_equal(s_, ref_s), (i, precision, hint)
+
+
+@pytest.mark.parametrize("precision", [1, 2, 5])
+@pytest.mark.parametrize("N,D,Hh,W,ci,co,layout", [
+    (1, 6, 16, 24, 32, 2, "ncdhw"),     # the network's last layer: GroupNorm + SiLU prologue, NCDHW fp32 output
+    (2, 5, 9, 12, 128, 1, "ndhwc"),     # learn_sigma off: one output channel; batch 2, ragged H / W, odd D
+    (1, 1, 8, 8, 48, 2, "ncdhw"),       # D = 1 (the 2-D model's last conv shape class)
+    (1, 19, 8, 16, 16, 2, "ndhwc"),     # several depth segments with a ragged last one
+])
+def test_conv3d_skinny_last_layer(hc, precision, N, D, Hh, W, ci, co, layout):
+    """3x3x3 convs with one or two output channels run on their own kernel (conv3d_skinny.hip: per input
+    voxel a 27*Cout-column GEMM, gathered along the three axes) -- vs F.conv3d, with the prologue
+    (affine + SiLU), both output layouts, in the f16x3 / f16 / bf16 arithmetic, bf16 source tensor,
+    and bit-exact on small-integer data."""
+    import guided_diffusion._hip as H
+    x = rnd(N, ci, D, Hh, W, seed=71)
+    w = rnd(co, ci, 3, 3, 3, seed=72, scale=0.05)
+    b = rnd(co, seed=73)
+    A = 1.0 + 0.1 * rnd(N, ci, seed=74)
+    B = 0.1 * rnd(N, ci, seed=75)
+    xs = hc.to_ndhwc(x)
+    if precision == 5:
+        xs = xs.to(torch.bfloat16)
+        x = hc.to_ncdhw(xs.float())
+    ref = F.conv3d(F.silu(x * A[:, :, None, None, None] + B[:, :, None, None, None]), w, b, padding=1)
+    out, _, _ = hc.conv3d([xs.cuda()], w.cuda(), b.cuda(), (D, Hh, W), aff=(A.cuda(), B.cuda()), act=H.ACT_SILU,
+                          out_layout=H.OUT_NCDHW if layout == "ncdhw" else H.OUT_NDHWC, want_stats=False,
+                          precision=precision)
+    got = out.cpu() if layout == "ncdhw" else hc.to_ncdhw(out.cpu())
+    assert torch.isfinite(got).all()
+    e = rel_err_per_channel(got.numpy(), ref.numpy())
+    assert e < {1: TOL, 2: 2e-3, 5: 1e-2}[precision], e
+    # no prologue, integer data: exact in every arithmetic
+    g = np.random.default_rng(9)
+    xi = torch.from_numpy(g.integers(-3, 4, (N, ci, D, Hh, W)).astype(np.float32))
+    wi = torch.from_numpy((2 * g.integers(-2, 3, (co, ci, 3, 3, 3))).astype(np.float32))
+    bi = torch.from_numpy(g.integers(-5, 6, (co,)).astype(np.float32))
+    out, _, _ = hc.conv3d([hc.to_ndhwc(xi).cuda()], wi.cuda(), bi.cuda(), (D, Hh, W), want_stats=False,
+                          precision=precision)
+    assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(xi, wi, bi, padding=1))
