@@ -412,7 +412,14 @@ class _Plan:
         wn = 4 if pc.Cout > 64 else (2 if pc.Cout > 32 else 1)
         tile = 8 if (d.H >= 8 and d.W >= 8) else 4
         flops = 2.0 * N * d.D * d.H * d.W * pc.Cout * d.Cin * pc.k ** 3
-        self.conv_meta[len(self.steps)] = ("conv3d_p%d_k%d_wn%d_t%d" % (pc_use.precision, pc.k, wn, tile), flops)
+        tag = "conv3d_p%d_k%d_wn%d_t%d" % (pc_use.precision, pc.k, wn, tile)
+        # (api.hip's rule for the one-or-two-cout kernel, conv3d_skinny.hip)
+        if (pc.k == 3 and pc.Cout <= 2 and d.in_mode == H.IN_SAME and d.C1 == 0 and not d.stats
+                and res_mode == H.RES_NONE and d.Cin in (32, 64, 128)
+                and ((pc_use.precision == H.PREC_BF16) == bool(d.io_dtype & H.IO_SRC0_BF16))
+                and pc_use.precision in (H.PREC_F16X3, H.PREC_F16, H.PREC_BF16)):
+            tag = "conv3d_p%d_k3_skinny" % pc_use.precision
+        self.conv_meta[len(self.steps)] = (tag, flops)
         self.steps.append((self.eng.lib.ddpm3d_conv3d, [C.byref(d), 0]))
         return d
 

@@ -308,6 +308,7 @@ def main():
             # PMC counters cannot be collected inside this process: the figure is the committed
             # rocprofv3 pass over this same workload, not a measurement of this run
             "traffic_static": traffic is not None,
+            "traffic_signature": sig,
             "peak_basis": kbasis,
             "launches_timed": cnt, "avg_launch_ms": round(ms / cnt, 4),
             "all_conv_kernels": {"achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),

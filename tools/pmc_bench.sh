@@ -21,8 +21,12 @@ out = sys.argv[1]
 
 def bench_name(k):
     """rocprof kernel name -> the name bench.py reports for that launch"""
-    if "conv3d_wz" in k:
-        return "conv3d_p3_k3_wn4_t8"
+    m = re.search(r"conv3d_wz_kernel<(\d+)", k)
+    if m:   # Winograd-D form of the f16x3 / f16 / bf16 arithmetic = precisions 3 / 4 / 6
+        return "conv3d_p%d_k3_wn4_t8" % {0: 3, 1: 4, 2: 6}[int(m.group(1))]
+    m = re.search(r"conv3d_skinny_kernel<(\d+)", k)
+    if m:
+        return "conv3d_p%d_k3_skinny" % {0: 1, 1: 2, 2: 5}[int(m.group(1))]
     m = re.search(r"conv3d_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", k)
     if m:
         prec, _pipe, ks, wn, _mt, txl, _tyl = map(int, m.groups())
@@ -43,7 +47,11 @@ for c, scale in (("FETCH_SIZE", 2.0 * 1024), ("WRITE_SIZE", 1024.0)):   # counte
         res[n][c.lower() + "_bytes_per_launch"] = sum(v) / len(v)
 for n, d in res.items():
     d["hbm_bytes_per_launch"] = d.get("fetch_size_bytes_per_launch", 0) + d.get("write_size_bytes_per_launch", 0)
-json.dump({"how": "tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
+sig = None
+for line in open(f"{out}/FETCH_SIZE.log"):
+    if line.startswith("{") and "traffic_signature" in line:
+        sig = json.loads(line)["roofline"]["traffic_signature"]
+json.dump({"signature": sig, "how": "tools/pmc_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over "
                   "bench.py --steps 1 --warmup 0 --ddpm-steps 2; FETCH_SIZE x2 (gfx950), KiB -> bytes",
            "kernels": res}, open(f"{out}/traffic.json", "w"), indent=1)
 for n, d in sorted(res.items()):
