@@ -95,21 +95,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         stage_write<MODE>(sl, raw, lds);
         __syncthreads();
 
-        // ---- 36 taps (j, dy, dx); weight ring of 3 taps, prefetch distance 2; the stream's byte
-        // offset is one running scalar (see conv3d_wzs.h)
+        // ---- 36 taps (j, dy, dx); weight ring of R taps, prefetch distance R - 1: 2 in the f16x3 form
+        // (a deeper one measured no different, and the registers are full), 7 in the one-MFMA-per-
+        // product forms, whose taps are three times shorter against the same L2 latency (r02, same
+        // box, bf16 DDIM-50: R = 3 / 4 / 6 / 8 / 9 -> 2.19 / 2.34 / 2.42 / 2.48 / 2.39 volumes/s; the
+        // A operands one tap ahead as below: two ahead -1.5 %, three -16 %).  The stream's byte
+        // offset is one running scalar
         unsigned woff = (unsigned)chunk * wchunk_stride;
         auto bump = [&]() {
             woff += wtap_stride;
             asm volatile("" : "+s"(woff));
         };
         constexpr int L = X3 ? 1 : 0;   // index of the lo halves (unused slot 0 alias in the f16 form)
-        u32x4 bq[3][X3 ? 2 : 1];
-        bq[0][0] = buffer_load16(wrsrc, wlane, woff);
-        if (X3) bq[0][L] = buffer_load16(wrsrc, wlane, woff + wpart);
-        bump();
-        bq[1][0] = buffer_load16(wrsrc, wlane, woff);
-        if (X3) bq[1][L] = buffer_load16(wrsrc, wlane, woff + wpart);
-        bump();
+        constexpr int R = X3 ? 3 : 8;
+        u32x4 bq[R][X3 ? 2 : 1];
+#pragma unroll
+        for (int s = 0; s < R - 1; ++s) {
+            bq[s][0] = buffer_load16(wrsrc, wlane, woff);
+            if (X3) bq[s][L] = buffer_load16(wrsrc, wlane, woff + wpart);
+            bump();
+        }
         h8 af[2][2][X3 ? 2 : 1];   // [slot][row tile][hi|lo]: A operands, read one tap ahead
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -130,19 +135,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
                     if (X3) af[t1 & 1][t][L] = *reinterpret_cast<const h8*>(bufc + arow[t] + off1 + 32);
                 }
             }
-            if (tap + 2 < NT) {
-                bq[(tap + 2) % 3][0] = buffer_load16(wrsrc, wlane, woff);
-                if (X3) bq[(tap + 2) % 3][L] = buffer_load16(wrsrc, wlane, woff + wpart);
+            if (tap + R - 1 < NT) {
+                bq[(tap + R - 1) % R][0] = buffer_load16(wrsrc, wlane, woff);
+                if (X3) bq[(tap + R - 1) % R][L] = buffer_load16(wrsrc, wlane, woff + wpart);
                 bump();
             }
             if constexpr (!IL) __builtin_amdgcn_sched_barrier(0);   // prefetches issue BEFORE this tap's MFMAs
             // next chunk's raw loads: after the chunk's last weight loads (vmcnt retires in order)
-            if (tap == NT - 3 && more) stage_issue(p, sl, raw, n, z0, chunk + 1);
+            if (tap == NT - R && more) stage_issue(p, sl, raw, n, z0, chunk + 1);
             const int j = tap / 9;
-            const h8 bhi = __builtin_bit_cast(h8, bq[tap % 3][0]);
+            const h8 bhi = __builtin_bit_cast(h8, bq[tap % R][0]);
             // per accumulator the order stays lo*hi, hi*lo, hi*hi; the two row tiles alternate
             if (X3) {
-                const h8 blo = __builtin_bit_cast(h8, bq[tap % 3][L]);
+                const h8 blo = __builtin_bit_cast(h8, bq[tap % R][L]);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
                     acc[j][t] = mfma16<false>(af[tap & 1][t][L], bhi, acc[j][t]);
