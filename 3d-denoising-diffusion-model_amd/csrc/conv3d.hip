@@ -220,27 +220,53 @@ __global__ __launch_bounds__(256, (PIPEM == 2 ? 1 : (TXL == 2 ? 2 : 3))) void co
         }
 
         // ------------------------------------------------ taps x k-steps
-        // weight ring of 3 taps (prefetch distance 2), statically indexed by the unrolled tap
+        // weight ring of R taps (prefetch distance R - 1), statically indexed by the unrolled tap
         const unsigned wchunk = (unsigned)chunk * wchunk_stride;  // scalar byte offset of this chunk
         constexpr bool LO = PREC != 2 && PREC != 5;  // PREC 2 / 5 stream only the hi halves
-        u32x4 bq[3][2];
-        bq[0][0] = buffer_load16(wrsrc, wlane, wchunk);
-        if (LO) bq[0][1] = buffer_load16(wrsrc, wlane, wchunk + wpart);
-        if (NT > 1) {
-            bq[1][0] = buffer_load16(wrsrc, wlane, wchunk + wtap_stride);
-            if (LO) bq[1][1] = buffer_load16(wrsrc, wlane, wchunk + wtap_stride + wpart);
+        constexpr int R = 3;   // (deeper: no gain in the f16x3 form, -3 % on one family in the bf16 form)
+        u32x4 bq[R][2];
+#pragma unroll
+        for (int s = 0; s < R - 1 && s < NT; ++s) {
+            bq[s][0] = buffer_load16(wrsrc, wlane, wchunk + s * wtap_stride);
+            if (LO) bq[s][1] = buffer_load16(wrsrc, wlane, wchunk + s * wtap_stride + wpart);
+        }
+        // split-f16 modes, 4x4 tiles and 1x1 convs: A operands read one tap ahead into a second register
+        // set (as in conv3d_wz.h), the tap boundary pinned so the scheduler does not sink the reads to
+        // their use: -19 % on the 4x4-level 3x3x3 convs, -2 % on the 1x1 convs (r02, same box).  Not on
+        // the 8x8-tile 3x3x3 form: three workgroups per CU leave 170 registers, it spills (+4 %).
+        constexpr bool AHEAD = PREC != 0 && (TXL == 2 || KS == 1);
+        h8 af[2][MT][2];
+        if constexpr (AHEAD) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                af[0][t][0] = *reinterpret_cast<const h8*>(lds + arow[t]);
+                if (LO) af[0][t][1] = *reinterpret_cast<const h8*>(lds + arow[t] + 32);
+            }
         }
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
-            if (tap + 2 < NT) {
-                bq[(tap + 2) % 3][0] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride);
-                if (LO) bq[(tap + 2) % 3][1] = buffer_load16(wrsrc, wlane, wchunk + (tap + 2) * wtap_stride + wpart);
+            if constexpr (AHEAD) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap + 1 < NT) {
+                    const int t1 = tap + 1;
+                    const int off1 = ((t1 / (KS * KS)) * RZ + ((t1 / KS) % KS) * RY + (t1 % KS) * VS) * 16;
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        af[t1 & 1][t][0] = *reinterpret_cast<const h8*>(lds + arow[t] + off1);
+                        if (LO) af[t1 & 1][t][1] = *reinterpret_cast<const h8*>(lds + arow[t] + off1 + 32);
+                    }
+                }
             }
+            if (tap + R - 1 < NT) {
+                bq[(tap + R - 1) % R][0] = buffer_load16(wrsrc, wlane, wchunk + (tap + R - 1) * wtap_stride);
+                if (LO) bq[(tap + R - 1) % R][1] = buffer_load16(wrsrc, wlane, wchunk + (tap + R - 1) * wtap_stride + wpart);
+            }
+            if constexpr (AHEAD) __builtin_amdgcn_sched_barrier(0);
             // all of this chunk's weight loads are in flight: now the next chunk's halo loads
-            if (PIPE && tap == (NT >= 3 ? NT - 3 : 0) && more) issue_raw(hs);
+            if (PIPE && tap == (NT >= R ? NT - R : 0) && more) issue_raw(hs);
             const int dz = tap / (KS * KS), dy = (tap / KS) % KS, dx = tap % KS;
             const int tapoff = (dz * RZ + dy * RY + dx * VS) * 16;
-            const u32x4 b0 = bq[tap % 3][0], b1 = LO ? bq[tap % 3][1] : b0;
+            const u32x4 b0 = bq[tap % R][0], b1 = LO ? bq[tap % R][1] : b0;
             if constexpr (PREC == 0) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
@@ -260,7 +286,7 @@ __global__ __launch_bounds__(256, (PIPEM == 2 ? 1 : (TXL == 2 ? 2 : 3))) void co
                 const h8 bhi = __builtin_bit_cast(h8, b0);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
-                    const h8 ahi = *reinterpret_cast<const h8*>(lds + arow[t] + tapoff);
+                    const h8 ahi = AHEAD ? af[tap & 1][t][0] : *reinterpret_cast<const h8*>(lds + arow[t] + tapoff);
                     acc[t] = mfma16<PREC == 5>(ahi, bhi, acc[t]);
                 }
             } else {
@@ -268,8 +294,8 @@ __global__ __launch_bounds__(256, (PIPEM == 2 ? 1 : (TXL == 2 ? 2 : 3))) void co
                 const h8 blo = __builtin_bit_cast(h8, b1);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
-                    const h8 ahi = *reinterpret_cast<const h8*>(lds + arow[t] + tapoff);
-                    const h8 alo = *reinterpret_cast<const h8*>(lds + arow[t] + tapoff + 32);
+                    const h8 ahi = AHEAD ? af[tap & 1][t][0] : *reinterpret_cast<const h8*>(lds + arow[t] + tapoff);
+                    const h8 alo = AHEAD ? af[tap & 1][t][1] : *reinterpret_cast<const h8*>(lds + arow[t] + tapoff + 32);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc[t], 0, 0, 0);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc[t], 0, 0, 0);
