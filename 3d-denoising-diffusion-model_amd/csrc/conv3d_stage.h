@@ -1,8 +1,8 @@
 // Lean staging of one (8x8x2-output tile, 16-channel chunk) item of the Winograd-D convolutions:
 // raw input planes -> GroupNorm/FiLM affine -> SiLU -> F(2,3) input transform along depth ->
-// f16 hi/lo split -> LDS image.  Shared by conv3d_wz.h and conv3d_wzs.h.
+// f16 hi/lo split -> LDS image, for conv3d_wz.h (split_pair also serves conv3d_skinny.hip).
 //
-// Why this file exists (r02, tools/wzs_stamps.py): in the wave-specialised kernel the LOADER waves
+// Why this file exists (r02, profiles/r02_wzs_stamps_*.txt): in r01's wave-specialised kernel the LOADER waves
 // were the critical path -- 8.2k cycles of staging per item against 7.7k cycles of tap loop, the
 // compute waves parked at the item barrier for 19-35 % of their life.  A wave issues in order at
 // ~4-5 cycles per instruction of ANY kind, and the staging code as compiled was ~1000 VALU plus ~700
