@@ -177,3 +177,34 @@ def test_full_size_winograd_kernel_vs_cpu_conv(ci, upsampled):
     got = hc.to_ncdhw(out.cpu())
     assert rel_err_per_channel(got.numpy(), ref.numpy()) < TOL
     check_stats(stats, ref)
+
+
+def test_script_patch_shape_96_cubed():
+    """The shape the reference's launcher really runs (test_DDPM_3d_mpi.sh / README.md: --large_size 96,
+    patches of 96^3, published architecture): resolutions 96 / 48 / 24 / 12 / 6, i.e. tile grids that
+    are NOT powers of two -- ragged 4x4 tiles at the 6x6 level (general epilogue), 12x12 = 1.5 8x8
+    tiles, odd workgroup counts for the XCD orders and the split-K model.  Default arithmetic vs the
+    exact-fp32 mode per output channel, bitwise repeatability, and one DDPM step through the fused
+    update."""
+    arch = dict(PUBLISHED, large_size=96, small_size=96)
+    shape = (1, 1, 96, 96, 96)
+    x, lr = inputs(shape)
+    t = torch.tensor([444])
+    model, diff = build(arch, "250")
+    with torch.no_grad():
+        y = model(x.cuda(), t.cuda(), low_res=lr.cuda())
+        y_again = model(x.cuda(), t.cuda(), low_res=lr.cuda())
+    assert tuple(y.shape) == (1, 2, 96, 96, 96) and torch.isfinite(y).all()
+    assert torch.equal(y, y_again)
+    out = diff.p_sample(model, x.cuda(), torch.tensor([249]).cuda(), model_kwargs={"low_res": lr.cuda()},
+                        noise=torch.from_numpy(synth.synth_noise(shape, 1, seed=5)[0]).cuda())
+    assert torch.isfinite(out["sample"]).all() and float(out["pred_xstart"].abs().max()) <= 1.0
+    y_def = y.cpu().numpy()
+    del model, y, y_again, out
+    torch.cuda.empty_cache()
+    exact, _ = build(arch, precision="f32")
+    with torch.no_grad():
+        y_exact = exact(x.cuda(), t.cuda(), low_res=lr.cuda()).cpu().numpy()
+    del exact
+    torch.cuda.empty_cache()
+    assert rel_err_per_channel(y_def, y_exact) < 1e-4
