@@ -108,3 +108,26 @@ def test_two_rank_run_equals_one_rank_and_loads_checkpoint(tmp_path):
     # synthetic-seed weights (no --model_path) are different weights: the checkpoint was really used
     c = np.load(_script().main(FLAGS + ["--base_samples", str(src), "--save_dir", str(tmp_path / "syn")]))["arr_0"]
     assert not np.array_equal(a, c)
+
+
+def test_c_abi_from_plain_cpp(tmp_path):
+    """The boundary is a C ABI, not a Python extension: tests/c_abi/conv_from_c.cpp (no Python, no torch:
+    hipMalloc'd buffers, `ddpm3d.h`, -lddpm3d) packs weights and runs one fused conv in the exact and the
+    f16x3 arithmetic, checks output and GroupNorm partial sums against a scalar host loop and the error
+    reporting path.  Compiled here with hipcc and run as a child process."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    csrc = os.path.join(PKG, "csrc")
+    exe = str(tmp_path / "conv_from_c")
+    cmd = [hipcc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "conv_from_c.cpp"),
+           "-L", csrc, "-lddpm3d", "-Wl,-rpath," + csrc, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "C ABI OK" in r.stdout
