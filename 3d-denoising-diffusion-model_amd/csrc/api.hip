@@ -155,10 +155,10 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         const long long b1 = vox * d->C1 * ((d->io_dtype & DDPM3D_IO_SRC1_BF16) ? 2 : 4);
         const size_t wb = ddpm3d_packed_bytes(d->Cout, d->Cin, d->ksize, d->precision);
         if (b0 >= 0xFFFFFFF0LL || b1 >= 0xFFFFFFF0LL || wb >= 0xFFFFFFF0ULL)
-            return fail(DDPM3D_EINVAL, "conv3d: a source tensor or the weights exceed 4 GiB; split the batch");
+            return fail(DDPM3D_E2BIG, "conv3d: a source tensor or the weights exceed 4 GiB; split the batch");
         // the epilogue addresses one SAMPLE of the output (or residual) with 32-bit offsets
         if ((long long)d->D * d->H * d->W * d->Cout * 4 >= 0xFFFFFFF0LL)
-            return fail(DDPM3D_EINVAL, "conv3d: one output sample exceeds 4 GiB; tile the volume");
+            return fail(DDPM3D_E2BIG, "conv3d: one output sample exceeds 4 GiB; tile the volume");
         k.src0_bytes = (unsigned)b0; k.src1_bytes = (unsigned)b1; k.w_bytes = (unsigned)wb;
         // workgroup -> XCD order: keep on one XCD whichever operand is the larger stream
         k.wstat = (d->kernel_hint & DDPM3D_HINT_WSTAT_ON)    ? 1
@@ -295,6 +295,15 @@ int ddpm3d_ddim_step(const float* model_out, const float* x, const float* noise,
     return launched(ddpm3d_launch_sample_step(true, model_out, x, noise, coef, t_idx, N, voxels, flags, eta,
                                               sample, pred_xstart, (hipStream_t)stream),
                     "ddim_step");
+}
+
+double ddpm3d_mfma_probe_flops_per_iter(int kind) { return ddpm3d_probe_flops_per_iter(kind); }
+
+int ddpm3d_mfma_probe(int kind, int iters, int blocks, float* out, uint64_t* clocks, void* stream) {
+    if (!out || !clocks || iters <= 0 || blocks <= 0 || ddpm3d_probe_flops_per_iter(kind) == 0.0)
+        return fail(DDPM3D_EINVAL, "mfma_probe: bad arguments (kind=%d iters=%d blocks=%d)", kind, iters, blocks);
+    return launched(ddpm3d_launch_mfma_probe(kind, iters, blocks, out, (unsigned long long*)clocks,
+                                             (hipStream_t)stream), "mfma_probe");
 }
 
 }  // extern "C"

@@ -503,9 +503,9 @@ static hipError_t launch_cfg(const ConvK& k, int grid_x, int grid_y, hipStream_t
     constexpr int HX = SXY * (TX - 1) + KS, HY = SXY * (TY - 1) + KS, HZ = TZ + 2 * PAD;
     constexpr size_t lds_bytes = (size_t)HZ * LdsGeom<TX, HX, HY>::RZ * 16;
     if constexpr (lds_bytes > 65536) {
-        static const hipError_t attr = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv3d_kernel<PREC, PIPE, KS, WN, MT, TXL, TYL>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        static DynLdsOnce once = {};
+        const hipError_t attr = ddpm3d_allow_dynamic_lds(
+            once, reinterpret_cast<const void*>(&conv3d_kernel<PREC, PIPE, KS, WN, MT, TXL, TYL>), (int)lds_bytes);
         if (attr != hipSuccess) return attr;
     }
     hipLaunchKernelGGL((conv3d_kernel<PREC, PIPE, KS, WN, MT, TXL, TYL>), dim3(grid_x, grid_y, k.ksplit), dim3(256),

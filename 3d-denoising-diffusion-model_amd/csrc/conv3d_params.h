@@ -136,6 +136,23 @@ static inline size_t ddpm3d_packed_bytes(int Cout, int Cin, int ksize, int prec)
     return prec != 0 ? body + (size_t)ddpm3d_cout_pad(Cout) * 4 : body;  // modes 1 and 2 share the image
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: raise it once
+// per (kernel instantiation, device), not once per process (a process that drives two GPUs would
+// otherwise fail its first > 64 KB launch on the second one).  `done` = one flag word per kernel.
+struct DynLdsOnce { unsigned long long mask[4]; };   // 256 devices
+static inline hipError_t ddpm3d_allow_dynamic_lds(DynLdsOnce& done, const void* kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    dev &= 255;
+    unsigned long long& w = done.mask[dev >> 6];
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&w, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) __atomic_fetch_or(&w, bit, __ATOMIC_RELEASE);
+    return e;
+}
+
 hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st);
 hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st);
 hipError_t ddpm3d_launch_conv_skinny(const ConvK& k, int prec, hipStream_t st);   // conv3d_skinny.hip

@@ -246,8 +246,9 @@ template <int MODE, int NCH, bool B16>
 static hipError_t sk_launch(const ConvK& k, dim3 grid, int zseg, int zsegs, hipStream_t st) {
     const size_t lds = skinny_lds_bytes(NCH * DDPM3D_CONV_CK);
     if (lds > 65536) {
-        static const hipError_t a = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3d_skinny_kernel<MODE, NCH, B16>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static DynLdsOnce once = {};
+        const hipError_t a = ddpm3d_allow_dynamic_lds(once, reinterpret_cast<const void*>(&conv3d_skinny_kernel<MODE, NCH, B16>),
+                                                      (int)lds);
         if (a != hipSuccess) return a;
     }
     hipLaunchKernelGGL((conv3d_skinny_kernel<MODE, NCH, B16>), grid, dim3(256), lds, st, k, zseg, zsegs);

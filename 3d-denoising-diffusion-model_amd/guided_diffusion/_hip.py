@@ -27,7 +27,7 @@ PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16, "bf16": PRE
 WINOGRAD_OF = {PREC_F16X3: PREC_F16X3_WZ, PREC_F16: PREC_F16_WZ, PREC_BF16: PREC_BF16_WZ}
 # ddpm3d_conv_desc.io_dtype bits: which activation tensors hold bf16
 IO_SRC0_BF16, IO_SRC1_BF16, IO_OUT_BF16, IO_RES_BF16 = 1, 2, 4, 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 # ddpm3d_conv_desc.kernel_hint bits (launch orders of identical arithmetic; tests and A/B measurements)
 HINT_WSTAT_OFF, HINT_WSTAT_ON = 0x100, 0x200
 
@@ -75,6 +75,8 @@ EXPORTS = {
     "ddpm3d_p_sample_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ddpm3d_ddim_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float,
                                    _fp, _fp, _fp]),
+    "ddpm3d_mfma_probe_flops_per_iter": (C.c_double, [C.c_int]),
+    "ddpm3d_mfma_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
 }
 
 _lib = None
@@ -101,9 +103,21 @@ def load():
     return lib
 
 
+E_INVAL, E_LAUNCH, E_NOSUP, E_2BIG = -1, -2, -3, -4
+PROBE_F16_32X32X16, PROBE_F16_16X16X32, PROBE_F32_32X32X2, PROBE_BF16_32X32X16, PROBE_BF16_16X16X32 = 0, 1, 2, 3, 4
+
+
+class Ddpm3dError(RuntimeError):
+    """A failed C-ABI call; `.code` is the DDPM3D_E* value it returned."""
+
+    def __init__(self, code, msg):
+        super().__init__("ddpm3d error %d: %s" % (code, msg))
+        self.code = code
+
+
 def check(rc):
     if rc != 0:
-        raise RuntimeError("ddpm3d error %d: %s" % (rc, load().ddpm3d_last_error().decode()))
+        raise Ddpm3dError(rc, load().ddpm3d_last_error().decode())
 
 
 def stream():

@@ -186,11 +186,14 @@ class UNetEngine:
         # two halves, recursively (>= 32 volumes of 64^3 on the published network).
         if N > self.split_above.get((D, Hh, W), 1 << 30):
             return self._forward_halves(x, low_res, film_rows, film_stride, out)
-        pl = self.plan(N, D, Hh, W)
         try:
+            # (a batch that cannot be addressed is refused while its plan is being built, at the first
+            # conv whose tensors pass 4 GiB -- conv_step applies the C ABI's own rule -- or, failing
+            # that, by the library with DDPM3D_E2BIG before anything is enqueued for that conv)
+            pl = self.plan(N, D, Hh, W)
             return pl.run(x, low_res, film_rows, film_stride, out)
-        except RuntimeError as e:
-            if N == 1 or "exceed 4 GiB" not in str(e):
+        except H.Ddpm3dError as e:
+            if N == 1 or e.code != H.E_2BIG:
                 raise
         self.plans.pop((N, D, Hh, W), None)
         self.split_above[(D, Hh, W)] = min(self.split_above.get((D, Hh, W), 1 << 30), N - 1)
@@ -374,6 +377,12 @@ class _Plan:
             d.Cin = d.C0 + d.C1
             if d.Cin != pc.Cin:
                 raise RuntimeError("conv %dx%d fed %d channels" % (pc.Cout, pc.Cin, d.Cin))
+        # the C ABI's addressing rule (api.hip: 32-bit byte offsets into each source tensor and into one
+        # output sample), applied here so an oversized batch is refused BEFORE its buffers are allocated
+        for s in ([] if planar else srcs):
+            if N * s.voxels * s.C * s.buf.element_size() >= 0xFFFFFFF0:
+                raise H.Ddpm3dError(H.E_2BIG, "a source tensor of %d x %d voxels x %d channels exceeds 4 GiB; "
+                                              "split the batch" % (N, s.voxels, s.C))
         if aff is not None:
             d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
         d.act = act

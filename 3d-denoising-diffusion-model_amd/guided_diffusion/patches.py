@@ -5,11 +5,15 @@ sampling hot path in the reference's inference script.
 Restated from scripts/test.py:185-246 (tiling), :248-262 (3-D Hann window),
 :92-146 (weighted overlap-add) and :283-301 (start positions).  scripts/test.py
 cannot be imported in the build container (it needs tifffile / mpi4py) and the
-reference holds no fixtures for it.  The three pure helpers (hann_window_3d,
-xy_starts, z_starts) are pinned to outputs of the reference's own function
-bodies (tests/golden/script_helpers.npz); the tiling and overlap-add, inline in
-the reference's main(), are checked against the constants and invariants the
-source states (tests/test_patches_cpu.py) -- PARITY UNPINNED for those.
+reference holds no fixtures for it, so every function here is pinned to
+outputs of the reference's OWN code, taken out of the script's syntax tree
+and run unchanged (tests/golden/make_golden.py): the three pure helpers
+(hann_window_3d, xy_starts, z_starts; script_helpers.npz) and the tiling /
+overlap-add loop nests that are inline in load_data_for_worker and main()
+(split_volume, stitch_patches; script_tiling.npz), bit for bit
+(tests/test_patches_cpu.py).  One intended difference: voxels whose total
+weight is 0 are 0 here, uninitialised memory in the reference (np.divide with
+`where` and no `out`).
 
 Host-side numpy on purpose: this is file-format glue around the GPU path (a
 200x200x130 volume is 5 M voxels), exactly where the reference has it.

@@ -39,13 +39,16 @@
 extern "C" {
 #endif
 
-#define DDPM3D_ABI_VERSION 9
+#define DDPM3D_ABI_VERSION 10
 
 enum {
     DDPM3D_OK = 0,
     DDPM3D_EINVAL = -1,   /* bad descriptor (shape / alignment / mode)        */
     DDPM3D_ELAUNCH = -2,  /* HIP refused the launch                           */
-    DDPM3D_ENOSUP = -3    /* valid request the library does not implement    */
+    DDPM3D_ENOSUP = -3,   /* valid request the library does not implement    */
+    DDPM3D_E2BIG = -4     /* a tensor of the call passes the 32-bit byte offsets the kernels
+                             address with (4 GiB): split the batch / tile the volume and
+                             call again -- nothing was enqueued                         */
 };
 
 /* input staging modes of ddpm3d_conv3d (where the conv's input voxel (z,y,x)
@@ -311,6 +314,27 @@ int ddpm3d_p_sample_step(const float* model_out, const float* x, const float* no
 int ddpm3d_ddim_step(const float* model_out, const float* x, const float* noise,
                      const float* coef, const int64_t* t_idx, int N, int voxels,
                      int flags, float eta, float* sample, float* pred_xstart, void* stream);
+
+/*
+ * Device calibration (measurement only; replaces nothing in the reference).  Enqueues a
+ * register-only MFMA loop -- no memory traffic, pseudo-random operands, `blocks` workgroups of four
+ * waves, each wave holding the dominant conv kernel's 64 x 32 x 4 fp32 accumulator tile -- so the
+ * caller can time what THIS device sustains on the matrix pipes under its power cap (boards of one
+ * pool differ by several per cent) and price a kernel against it (bench.py:
+ * roofline.device_sustained_tflops).  out: blocks*256 floats (checksums, keeps the loop alive);
+ * clocks: blocks*2 uint64 = {shader cycles, 100 MHz ticks} spent in the loop per workgroup
+ * (in-kernel clock = cycles / ticks * 0.1 GHz).  FLOPs issued = blocks * iters *
+ * ddpm3d_mfma_probe_flops_per_iter(kind).
+ */
+enum {
+    DDPM3D_PROBE_F16_32X32X16 = 0,   /* v_mfma_f32_32x32x16_f16: what the f16x3 / f16 convs issue */
+    DDPM3D_PROBE_F16_16X16X32 = 1,   /* v_mfma_f32_16x16x32_f16                                  */
+    DDPM3D_PROBE_F32_32X32X2 = 2,    /* v_mfma_f32_32x32x2_f32: the exact mode                    */
+    DDPM3D_PROBE_BF16_32X32X16 = 3,
+    DDPM3D_PROBE_BF16_16X16X32 = 4
+};
+double ddpm3d_mfma_probe_flops_per_iter(int kind);
+int ddpm3d_mfma_probe(int kind, int iters, int blocks, float* out, uint64_t* clocks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -283,6 +283,110 @@ def gen_script_helpers():
     save("script_helpers.npz", **out)
 
 
+def _script_nests():
+    """The two loop nests of scripts/test.py that tile a volume into patches (inside
+    load_data_for_worker, :214-231) and blend the denoised patches back (inside main(), :113-146 with
+    the normalising np.divide), lifted out of the script's syntax tree UNCHANGED and compiled as they
+    stand.  Returns (helpers namespace, tiling code, stitching code)."""
+    import ast
+    from guided_diffusion import logger as ref_logger
+    path = "/root/reference/scripts/test.py"
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    funcs = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
+    helpers = ast.Module(body=[funcs[k] for k in ("create_3d_hann_window", "_calculate_xy_starts_fixed",
+                                                  "_calculate_z_starts_with_overlap")], type_ignores=[])
+    ns = {"np": np, "logger": ref_logger}
+    exec(compile(helpers, path, "exec"), ns)
+
+    def x_nest(fn):
+        found = [n for n in ast.walk(fn) if isinstance(n, ast.For) and getattr(n.target, "id", "") == "x_start"]
+        assert len(found) == 1
+        return found[0]
+
+    tile_for = x_nest(funcs["load_data_for_worker"])
+    stitch_for = x_nest(funcs["main"])
+    divide = [n for n in ast.walk(funcs["main"]) if isinstance(n, ast.Assign)
+              and getattr(n.targets[0], "id", "") == "arr_result" and isinstance(n.value, ast.Call)
+              and getattr(n.value.func, "attr", "") == "divide"]
+    assert len(divide) == 1
+    tile = compile(ast.Module(body=[tile_for], type_ignores=[]), path, "exec")
+    stitch = compile(ast.Module(body=[stitch_for, divide[0]], type_ignores=[]), path, "exec")
+    return ns, tile, stitch
+
+
+def _run_script_tiling(vol, resolution, denoise):
+    """vol (D,H,W) float32 -> what the reference's two nests produce around `denoise`
+    (a stand-in for the sampler: patch index, (1,1,Z,H,W) array -> same shape)."""
+    ns, tile, stitch = _script_nests()
+    D, H, W = vol.shape
+    env = dict(ns)
+    env.update(vol=vol, resolution=resolution, H=H, W=W, D=D, image_arr=[],
+               x_starts=ns["_calculate_xy_starts_fixed"](H, resolution, num_patches=3),
+               y_starts=ns["_calculate_xy_starts_fixed"](W, resolution, num_patches=3),
+               z_starts=ns["_calculate_z_starts_with_overlap"](D, resolution))
+    exec(tile, env)                                       # scripts/test.py:214-231
+    image_arr = np.array(env["image_arr"])                # (P, H, W, Z), scripts/test.py:233
+    samples = []
+    for i in range(len(image_arr)):
+        # :243-245 (H,W,Z) -> (1,1,Z,H,W); the sampler; :72 (B,1,Z,H,W) -> (B,1,H,W,Z)
+        batch = torch.from_numpy(np.stack([image_arr[i]])).float().permute(0, 3, 1, 2).unsqueeze(1)
+        out = denoise(i, batch.numpy())
+        samples.append(torch.from_numpy(out).permute(0, 1, 3, 4, 2).contiguous().numpy())
+    arr = np.concatenate(samples, axis=0)                 # :89
+    env2 = dict(ns)
+    env2.update(arr=arr, resolution=resolution, original_height=H, original_width=W, original_depth=D,
+                arr_result=np.zeros((H, W, D), dtype=np.float32), x_starts=env["x_starts"],
+                y_starts=env["y_starts"], z_starts=env["z_starts"],
+                hann_window=ns["create_3d_hann_window"](resolution), patch_idx=0)
+    env2["weight_arr"] = np.zeros_like(env2["arr_result"], dtype=np.float32)
+    exec(stitch, env2)                                    # :113-146
+    return image_arr, arr, env2["arr_result"], env2["weight_arr"]
+
+
+def script_denoiser(i, batch):
+    """Deterministic stand-in for the sampler so that overlapping patches DISAGREE (a blend of equal
+    values would not test the weights): patch i -> 0.5 * patch + 0.01 * i."""
+    return (batch * np.float32(0.5) + np.float32(0.01 * i)).astype(np.float32)
+
+
+def gen_script_tiling():
+    """Pins patches.split_volume / stitch_patches: the reference's own tiling and
+    Hann overlap-add loops run on seeded volumes.  Small case: everything stored.  The launcher's real
+    geometry (110 x 200 x 200, 96^3 patches: 18 patches = 64 MB) is stored as per-patch checksums and a
+    strided sample of the stitched volume.  Where the total weight is 0 the reference's
+    np.divide(..., where=weight > 0) leaves UNINITIALISED memory; the fixture stores the weights so
+    the test compares only where they are positive."""
+    out = {}
+    rng = np.random.default_rng(7)
+    vol = (rng.random((22, 40, 40), dtype=np.float32) * 4.0).astype(np.float32)
+    image_arr, arr, res, wsum = _run_script_tiling(vol, 16, script_denoiser)
+    out["small_vol"] = vol
+    out["small_patches_hwz"] = image_arr
+    out["small_result"] = np.where(wsum > 0, res, 0).astype(np.float32)
+    out["small_weight"] = wsum
+    # ragged: a volume the patch grid does not cover evenly and that is SHORTER than a patch along z
+    vol2 = (rng.random((13, 40, 37), dtype=np.float32) * 4.0).astype(np.float32)
+    image_arr2, _, res2, wsum2 = _run_script_tiling(vol2, 16, script_denoiser)
+    out["ragged_vol"] = vol2
+    out["ragged_patches_hwz"] = image_arr2
+    out["ragged_result"] = np.where(wsum2 > 0, res2, 0).astype(np.float32)
+    out["ragged_weight"] = wsum2
+    # the launcher's geometry
+    rng = np.random.default_rng(8)
+    big = (rng.random((110, 200, 200), dtype=np.float32) * 4.0).astype(np.float32)
+    image_arr3, _, res3, wsum3 = _run_script_tiling(big, 96, script_denoiser)
+    out["big_seed_shape"] = np.array([8, 110, 200, 200], dtype=np.int64)
+    out["big_patch_sums"] = image_arr3.reshape(len(image_arr3), -1).astype(np.float64).sum(1)
+    out["big_patch_corner"] = image_arr3[:, :4, :4, :4].copy()
+    out["big_patch_last"] = image_arr3[:, -3:, -3:, -3:].copy()
+    out["big_result_strided"] = np.where(wsum3 > 0, res3, 0).astype(np.float32)[::7, ::7, ::5]
+    out["big_weight_strided"] = wsum3[::7, ::7, ::5]
+    out["big_result_sum"] = np.array([np.where(wsum3 > 0, res3, 0).astype(np.float64).sum(),
+                                      wsum3.astype(np.float64).sum()])
+    save("script_tiling.npz", **out)
+
+
 def model2d_flags(**over):
     """create_model_and_diffusion's flag set (script_util.py:41-66) at a CPU-sized 2-D RGB network:
     attention at ds 4 and in the middle block, conv down/upsampling (resblock_updown False)."""
@@ -324,7 +428,7 @@ def gen_model2d():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "temb", "keys", "resblocks", "unet", "sampler", "helpers", "model2d"]
+    which = sys.argv[1:] or ["schedules", "temb", "keys", "resblocks", "unet", "sampler", "helpers", "tiling", "model2d"]
     if "schedules" in which:
         gen_schedules()
     if "temb" in which:
@@ -341,5 +445,7 @@ if __name__ == "__main__":
         gen_model2d()
     if "helpers" in which:
         gen_script_helpers()
+    if "tiling" in which:
+        gen_script_tiling()
     if "sampler250" in which:       # ~10 CPU-minutes; not part of the default list
         gen_sampler_published250()

@@ -2,11 +2,12 @@
 Patch tiler / Hann stitcher / volume I/O (guided_diffusion/patches.py).
 
 The reference script (scripts/test.py) cannot be imported in the build container (tifffile / mpi4py)
-and holds no fixtures.  Its three PURE helpers -- the Hann window and the two start-position rules
--- are pinned to outputs of the reference's own function bodies (tests/golden/script_helpers.npz,
-tests/golden/make_golden.py::gen_script_helpers); the tiling / overlap-add around them, which the
-reference only has inline in main(), stays checked against the constants its source states and
-against invariants of the algorithm (PARITY UNPINNED for those).
+and holds no fixtures.  Everything here is pinned to outputs of the reference's OWN code, lifted out
+of the script's syntax tree and executed unchanged by tests/golden/make_golden.py: the three pure
+helpers -- Hann window, the two start-position rules -- (script_helpers.npz) and the two loop nests
+around them, the tiling of load_data_for_worker (:214-231) and the Hann overlap-add of main()
+(:113-146) (script_tiling.npz).  The one intended difference: where the total weight is 0 the
+reference's np.divide(..., where=...) leaves uninitialised memory, this package writes 0.
 """
 
 import numpy as np
@@ -26,6 +27,59 @@ def test_pure_helpers_vs_reference_golden(golden):
     w = patches.hann_window_3d(96)
     assert np.array_equal(w[48], g["hann96_mid_plane"])
     assert np.allclose([w.min(), w.max(), w.mean(), w.sum()], g["hann96_stats"], rtol=1e-12, atol=0)
+
+
+def _denoise(i, batch):
+    """the stand-in for the sampler the fixture was generated with (make_golden.py: script_denoiser)"""
+    return (batch * np.float32(0.5) + np.float32(0.01 * i)).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["small", "ragged"])
+def test_tiling_vs_reference_golden(golden, case):
+    """split_volume == the reference's own patch extraction / zero padding / (Z,H,W)->(H,W,Z) nest."""
+    g = golden("script_tiling.npz")
+    vol, ref = g[case + "_vol"], g[case + "_patches_hwz"]
+    p, grid = patches.split_volume(vol, 16)
+    assert p.shape == (len(ref), 1, 16, 16, 16)
+    got = p[:, 0].transpose(0, 2, 3, 1)                 # (Z,H,W) -> (H,W,Z), scripts/test.py:230
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("case", ["small", "ragged"])
+def test_stitching_vs_reference_golden(golden, case):
+    """stitch_patches == the reference's weighted overlap-add and normalisation, bit for bit wherever
+    the total weight is positive; 0 (not uninitialised memory) elsewhere."""
+    g = golden("script_tiling.npz")
+    vol, ref, wref = g[case + "_vol"], g[case + "_result"], g[case + "_weight"]
+    p, grid = patches.split_volume(vol, 16)
+    den = [_denoise(i, p[i:i + 1])[0, 0].transpose(1, 2, 0) for i in range(len(p))]   # (H,W,Z), :72
+    out, wsum = patches.stitch_patches(den, grid, vol.shape, 16)
+    assert np.array_equal(wsum, wref)
+    assert np.array_equal(out[wref > 0], ref[wref > 0])
+    assert np.all(out[wref == 0] == 0)
+    assert (wref == 0).any() and (wref > 0).mean() > 0.7
+
+
+def test_launcher_geometry_vs_reference_golden(golden):
+    """The reference launcher's real shape (110 x 200 x 200 volume, 96^3 patches, 18 of them):
+    per-patch checksums and corners of the tiling, a strided sample of the stitched volume."""
+    g = golden("script_tiling.npz")
+    seed, D, Hh, W = (int(v) for v in g["big_seed_shape"])
+    rng = np.random.default_rng(seed)
+    vol = (rng.random((D, Hh, W), dtype=np.float32) * 4.0).astype(np.float32)
+    p, grid = patches.split_volume(vol, 96)
+    hwz = p[:, 0].transpose(0, 2, 3, 1)
+    assert len(grid) == 18
+    assert np.array_equal(hwz.reshape(18, -1).astype(np.float64).sum(1), g["big_patch_sums"])
+    assert np.array_equal(hwz[:, :4, :4, :4], g["big_patch_corner"])
+    assert np.array_equal(hwz[:, -3:, -3:, -3:], g["big_patch_last"])
+    den = [_denoise(i, p[i:i + 1])[0, 0].transpose(1, 2, 0) for i in range(len(p))]
+    out, wsum = patches.stitch_patches(den, grid, vol.shape, 96)
+    ws = g["big_weight_strided"]
+    assert np.array_equal(wsum[::7, ::7, ::5], ws)
+    assert np.array_equal(out[::7, ::7, ::5][ws > 0], g["big_result_strided"][ws > 0])
+    assert np.allclose([out.astype(np.float64).sum(), wsum.astype(np.float64).sum()], g["big_result_sum"],
+                       rtol=1e-12, atol=0)
 
 
 def test_start_positions_match_the_reference_constants():
