@@ -171,6 +171,7 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
                                   (size_t)ddpm3d_cout_pad(d->Cout) * 4);
     if (d->stats && d->stats_rows != k.stats_rows)
         return fail(DDPM3D_EINVAL, "conv3d: stats_rows=%d, this shape writes %d", d->stats_rows, k.stats_rows);
+    if (d->stats && !aligned16(d->stats)) return fail(DDPM3D_EINVAL, "conv3d: stats must be 16-byte aligned");
     if (d->stats && d->out_layout != DDPM3D_OUT_NDHWC)
         return fail(DDPM3D_EINVAL, "conv3d: statistics only with NDHWC output");
     const long long blocks = (long long)k.N * k.tilesZ * k.tilesY * k.tilesX;
@@ -185,13 +186,15 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     return launched(ddpm3d_launch_splitk_reduce(k, (hipStream_t)stream), "conv3d split-K reduce");
 }
 
-int ddpm3d_gn_finalize(const float* stats0, int C0, int rows0, const float* stats1, int C1, int rows1,
+int ddpm3d_gn_finalize(const double* stats0, int C0, int rows0, const double* stats1, int C1, int rows1,
                        int N, int groups, double count, float eps, const float* gamma, const float* beta,
                        const float* film, int film_stride, int film_off, float* aff_a, float* aff_b,
                        float* bound, void* stream) {
     const int C = C0 + C1;
     if (!stats0 || N <= 0 || groups <= 0 || C0 <= 0 || C1 < 0 || rows0 <= 0 || count <= 0)
         return fail(DDPM3D_EINVAL, "gn_finalize: bad arguments");
+    if (!aligned16(stats0) || (stats1 && !aligned16(stats1)))
+        return fail(DDPM3D_EINVAL, "gn_finalize: statistics must be 16-byte aligned");
     if (gamma ? (!beta || !aff_a || !aff_b) : !bound)
         return fail(DDPM3D_EINVAL, "gn_finalize: gamma needs beta, aff_a, aff_b; without gamma only `bound` is written");
     if (C % groups) return fail(DDPM3D_EINVAL, "gn_finalize: C=%d not divisible by %d groups", C, groups);
@@ -211,8 +214,8 @@ int ddpm3d_absmax(const float* x0, const float* x1, int N, size_t per_sample, fl
 
 int ddpm3d_gn_stats_rows(int voxels) { return voxels > 0 ? ddpm3d_gn_stats_rows_impl(voxels) : 0; }
 
-int ddpm3d_gn_stats(const float* x, int N, int voxels, int C, float* stats, void* stream) {
-    if (!x || !stats || N <= 0 || voxels <= 0 || C <= 0 || (C & 3) || !aligned16(x))
+int ddpm3d_gn_stats(const float* x, int N, int voxels, int C, double* stats, void* stream) {
+    if (!x || !stats || N <= 0 || voxels <= 0 || C <= 0 || (C & 3) || !aligned16(x) || !aligned16(stats))
         return fail(DDPM3D_EINVAL, "gn_stats: bad arguments (C must be a multiple of 4, x 16-byte aligned)");
     return launched(ddpm3d_launch_gn_stats(x, N, voxels, C, stats, (hipStream_t)stream), "gn_stats");
 }

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) 
     const size_t slab_stride = (size_t)p.N * DHW * p.Cout;
     for (int cout = threadIdx.x; cout < p.Cout; cout += 256) {
         const float bias = p.bias[(size_t)n * p.bias_stride_n + cout];
-        float s1 = 0.0f, s2 = 0.0f;
+        double s1 = 0.0, s2 = 0.0;
         for (size_t v = v0; v < v1; ++v) {
             const size_t e = ((size_t)n * DHW + v) * p.Cout + cout;
             float val = p.partial[e];
@@ -346,13 +346,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) 
                 ddpm3d_act_store(p.out, e, val, (p.io & DDPM3D_IO_OUT_BF16) != 0);
             else
                 p.out[((size_t)n * p.Cout + cout) * DHW + v] = val;
-            s1 += val;
-            s2 = fmaf(val, val, s2);
+            gn_sums_add(s1, s2, val);
         }
-        if (p.stats != nullptr) {
-            float2 v2 = make_float2(s1, s2);
-            *reinterpret_cast<float2*>(p.stats + (((size_t)n * p.Cout + cout) * rows + r) * 2) = v2;
-        }
+        if (p.stats != nullptr)
+            *reinterpret_cast<double2*>(p.stats + (((size_t)n * p.Cout + cout) * rows + r) * 2) = make_double2(s1, s2);
     }
 }
 
@@ -371,11 +368,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK 
     const size_t slab_stride = (size_t)p.N * DHW * p.Cout;
     const int quads = p.Cout / 4;
     const int cq = threadIdx.x & 63, vl = threadIdx.x >> 6;
-    __shared__ float red[2][4][64 * 4];
+    __shared__ double red[2][4][64 * 4];
     {
         const int q = blockIdx.y * 64 + cq;
         const bool qok = q < quads;
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
         if (qok) {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + (size_t)n * p.bias_stride_n + q * 4);
 #pragma unroll
@@ -405,8 +402,8 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK 
                             u32x2{bf16_pack(val[0], val[1]), bf16_pack(val[2], val[3])};
                     else
                         *reinterpret_cast<f32x4*>(p.out + e) = val;
-                    s1 += val;
-                    s2 += val * val;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gn_sums_add(s1[c], s2[c], val[c]);
                 }
             }
         }
@@ -420,12 +417,12 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK 
             if (vl == 0 && qok) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float a = (red[0][0][cq * 4 + c] + red[0][1][cq * 4 + c]) +
-                                    (red[0][2][cq * 4 + c] + red[0][3][cq * 4 + c]);
-                    const float b = (red[1][0][cq * 4 + c] + red[1][1][cq * 4 + c]) +
-                                    (red[1][2][cq * 4 + c] + red[1][3][cq * 4 + c]);
-                    *reinterpret_cast<float2*>(p.stats + (((size_t)n * p.Cout + q * 4 + c) * rows + r) * 2) =
-                        make_float2(a, b);
+                    const double a = (red[0][0][cq * 4 + c] + red[0][1][cq * 4 + c]) +
+                                     (red[0][2][cq * 4 + c] + red[0][3][cq * 4 + c]);
+                    const double b = (red[1][0][cq * 4 + c] + red[1][1][cq * 4 + c]) +
+                                     (red[1][2][cq * 4 + c] + red[1][3][cq * 4 + c]);
+                    *reinterpret_cast<double2*>(p.stats + (((size_t)n * p.Cout + q * 4 + c) * rows + r) * 2) =
+                        make_double2(a, b);
                 }
             }
             __syncthreads();
@@ -471,16 +468,26 @@ hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st) 
 // Winograd-D forms of the f16x3 / f16 / bf16 3x3x3 conv, an object of their own (conv3d_p3.o;
 // eligibility is checked by the C ABI)
 #include "conv3d_wz.h"
-
 hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t st) {
     const int gy = k.CoutPad / 128;
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
+#ifdef DDPM3D_WZ_STAMPS
+    constexpr size_t lds = (size_t)WzGeom::BUF + 4 * WZ_NSTAMP * 8;
+#else
     constexpr size_t lds = (size_t)WzGeom::BUF;
+#endif
     // One kernel form.  Measured and dropped in r02 (profiles/r02_layer_ab_*.txt, r02_wzp_plane_pair_*.txt,
     // DESIGN.md 3.1b): a wave-specialised persistent form (compute waves + loader waves, tile walk,
     // epilogue hand-off through LDS); a 128-row wave tile with one wave per SIMD (plain, and with the
     // staging interleaved into the tap loop); a plane-pair form (8x8x4 tiles, two anti-phase halves of
     // two transformed planes each, half the L2 weight stream) -- 0-15 % behind this one or equal to it.
+    // r03: the plane-pair form rebuilt for the one-MFMA modes (f16, bf16), where the L2 weight stream
+    // was suspected to be the bound, at weight-ring depths 3 / 4 / 5 / 6 / 8, bit-identical:
+    // 15-30 % SLOWER than this form on the 64^3 and 64x32x32 layers, equal below
+    // (profiles/r03_layer_ab_plane_pair_{bf16,f16}.txt) -- with a third of the MFMAs its tap phase
+    // (72 MFMAs) is shorter than the other half's staging phase, so the anti-phase halves wait for each
+    // other.  Not kept (the form is commit 8797410's conv3d_wzp.h with the weight-ring depth made a template
+    // parameter).
     // f16x3: the issue order of a tap (interleaved / clumped prefetches) by shape, as measured
     // (profiles/r02_layer_ab_wz_interleave.txt): interleaved except for the 384-cout layers.
     if (c.PREC == DDPM3D_PREC_F16_WZ)

@@ -96,7 +96,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
             };
             roff_ = cvalid ? rbase : DDPM3D_OOB_OFFSET;
             const float bias = (!split && cvalid) ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
-            float s1 = 0.0f, s2 = 0.0f;
+            double s1 = 0.0, s2 = 0.0;   // GroupNorm partial sums in fp64 (gn_sums_add below)
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 unsigned soff[16];
@@ -139,8 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                     if (!split) {
                         val += bias;
                         if (resid) val += r[reg];
-                        s1 += val;
-                        s2 = fmaf(val, val, s2);
+                        gn_sums_add(s1, s2, val);
                     }
                     if (o16)
                         __builtin_amdgcn_raw_buffer_store_b16(ddpm3d_to_bf16(val), drsrc, voff, soff[reg], 0);
@@ -153,8 +152,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 s2 += __shfl_xor(s2, 32);
                 if (half == 0 && cvalid) {
                     const size_t row = (size_t)tile_in_n * WM + wm;
-                    *reinterpret_cast<float2*>(p.stats + (((size_t)n * p.Cout + cout) * p.stats_rows + row) * 2) =
-                        make_float2(s1, s2);
+                    *reinterpret_cast<double2*>(p.stats + (((size_t)n * p.Cout + cout) * p.stats_rows + row) * 2) =
+                        make_double2(s1, s2);
                 }
             }
             return;
@@ -180,7 +179,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
         return;
     }
     const float bias = cvalid ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
-    float s1 = 0.0f, s2 = 0.0f;
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -198,8 +197,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                     ddpm3d_act_store(p.out, ((size_t)n * DHW + vox) * p.Cout + cout, val, (p.io & DDPM3D_IO_OUT_BF16) != 0);
                 else
                     p.out[((size_t)n * p.Cout + cout) * DHW + vox] = val;
-                s1 += val;
-                s2 = fmaf(val, val, s2);
+                gn_sums_add(s1, s2, val);
             }
         }
     }
@@ -209,8 +207,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
         if (half == 0 && cvalid) {
             // channel-major [N][Cout][rows][2]: a GroupNorm group's partial sums are contiguous
             const size_t row = (size_t)tile_in_n * WM + wm;
-            float2 v2 = make_float2(s1, s2);
-            *reinterpret_cast<float2*>(p.stats + (((size_t)n * p.Cout + cout) * p.stats_rows + row) * 2) = v2;
+            *reinterpret_cast<double2*>(p.stats + (((size_t)n * p.Cout + cout) * p.stats_rows + row) * 2) =
+                make_double2(s1, s2);
         }
     }
 }

@@ -24,7 +24,7 @@ struct ConvK {
     const float* bias;
     const float* res;
     float* out;
-    float* stats;
+    double* stats;   // [N][Cout][stats_rows][2] fp64 (sum, sum of squares)
     float* partial;  // split-K slabs [ksplit][N*D*H*W][Cout], raw accumulators
     const float* wscale;  // split-f16 modes: per-cout 1 / weight scale
     const float* in_bound;    // ddpm3d_conv_desc.in_bound (split-f16 modes)
@@ -157,6 +157,17 @@ hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st);
 hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st);
 hipError_t ddpm3d_launch_conv_skinny(const ConvK& k, int prec, hipStream_t st);   // conv3d_skinny.hip
 bool ddpm3d_skinny_ok(int CinPad, int prec, bool src_bf16);
+
+// GroupNorm partial sums are accumulated and stored in fp64 (r03).  With fp32 sums the variance
+// E[x^2] - mean^2 loses |mean|^2 / var x 1e-7 of its value to cancellation -- invisible on
+// normalised data, 1e-2 on a tensor whose mean is 300 standard deviations (un-normalised PET counts
+// behind the first conv, scripts/test.py:201-203).  fp64 add / fma issue at the fp32 rate on gfx950;
+// per stored element this is one conversion more than the fp32 form.
+__device__ __forceinline__ void gn_sums_add(double& s1, double& s2, float val) {
+    const double v = (double)val;
+    s1 += v;
+    s2 = __builtin_fma(v, v, s2);
+}
 
 // Residual term of the conv epilogue for output element (n, z, y, x, cout);
 // shared by the conv kernel and the split-K reduce kernel.

@@ -32,6 +32,16 @@
 // WZ_BF16: one bf16 MFMA on bf16-rounded operands, no scaling (DDPM3D_PREC_BF16_WZ)
 // IL: the next tap's LDS reads and weight loads are spread between this tap's MFMAs
 // (sched_group_barrier) instead of issued in front of them
+// Measurement build only (-DDDPM3D_WZ_STAMPS, tools/wz_stamps.py; never in the shipped library): s_memtime
+// stamps of every phase of every wave, kept in LDS behind the image and dumped to ddpm3d_conv_desc.workspace
+// when the wave ends: [workgroup][wave][WZ_NSTAMP] uint64.
+#ifdef DDPM3D_WZ_STAMPS
+#define WZ_NSTAMP 48
+#define WZ_STAMP(i) do { if (lane == 0) wz_stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WZ_STAMP(i) do { } while (0)
+#endif
+
 template <int MODE, int IL = 0>
 __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     constexpr bool X3 = MODE == WZ_F16X3;
@@ -45,6 +55,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     const int lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
+#ifdef DDPM3D_WZ_STAMPS
+    unsigned long long* wz_stamps = reinterpret_cast<unsigned long long*>(lds + WzGeom::BUF) + wn * WZ_NSTAMP;
+    WZ_STAMP(0);
+#endif
 
     const WgId wg = wg_id(p);
     int tile = wg.tile;
@@ -87,13 +101,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     stage_zero_border(sl, lds, 1, tid);
     StageRaw raw;
     if (chunk_begin < chunk_end) stage_issue(p, sl, raw, n, z0, chunk_begin);
+    WZ_STAMP(1);
 
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         const bool more = chunk + 1 < chunk_end;
         const unsigned char* bufc = lds;
+        WZ_STAMP(2 + (chunk - chunk_begin) * 5);
         __syncthreads();
+        WZ_STAMP(3 + (chunk - chunk_begin) * 5);
         stage_write<MODE>(sl, raw, lds);
+        WZ_STAMP(4 + (chunk - chunk_begin) * 5);
         __syncthreads();
+        WZ_STAMP(5 + (chunk - chunk_begin) * 5);
 
         // ---- 36 taps (j, dy, dx); weight ring of R taps, prefetch distance R - 1: 2 in the f16x3 form
         // (a deeper one measured no different, and the registers are full), 7 in the one-MFMA-per-
@@ -171,7 +190,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
                 }
             }
         }
+        WZ_STAMP(6 + (chunk - chunk_begin) * 5);
     }
+    WZ_STAMP(42);
 
     // ---- output transform (register-local), then the common epilogue on the 8x8x2 tile:
     // virtual accumulator u = zbit*2 + t covers rows m = u*32 + row -> (tz = zbit, ty, tx)
@@ -183,4 +204,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     }
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
     conv_epilogue<1, 1, 4, TXL, TYL>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split, asc.inv);
+#ifdef DDPM3D_WZ_STAMPS
+    WZ_STAMP(43);
+    if (lane == 0) {
+        wz_stamps[44] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        wz_stamps[45] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+        wz_stamps[46] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (p.partial != nullptr && lane < WZ_NSTAMP) {
+        const size_t wgl = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        reinterpret_cast<unsigned long long*>(p.partial)[(wgl * 4 + wn) * WZ_NSTAMP + lane] = wz_stamps[lane];
+    }
+#endif
 }

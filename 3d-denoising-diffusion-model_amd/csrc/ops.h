@@ -4,14 +4,14 @@
 #include <stdint.h>
 
 hipError_t ddpm3d_launch_pack(const float* w, int Cout, int Cin, int ks, int prec, void* out, hipStream_t st);
-hipError_t ddpm3d_launch_gn_finalize(const float* st0, int C0, int rows0, const float* st1, int C1,
+hipError_t ddpm3d_launch_gn_finalize(const double* st0, int C0, int rows0, const double* st1, int C1,
                                      int rows1, int N, int groups, double count, float eps,
                                      const float* gamma, const float* beta, const float* film,
                                      int film_stride, int film_off, float* A, float* B, float* bound,
                                      hipStream_t st);
 hipError_t ddpm3d_launch_absmax(const float* x0, const float* x1, int N, size_t per_sample, float* bound,
                                 hipStream_t st);
-hipError_t ddpm3d_launch_gn_stats(const float* x, int N, int voxels, int C, float* stats, hipStream_t st);
+hipError_t ddpm3d_launch_gn_stats(const float* x, int N, int voxels, int C, double* stats, hipStream_t st);
 int ddpm3d_gn_stats_rows_impl(int voxels);
 hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, const float* freqs,
                                             float* out, hipStream_t st);

@@ -193,7 +193,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // One workgroup per (n, group): fold partial (sum, sumsq) rows in fp64, then
 // write A, B for the group's channels.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(
-    const float* __restrict__ st0, int C0, int rows0, const float* __restrict__ st1, int C1, int rows1,
+    const double* __restrict__ st0, int C0, int rows0, const double* __restrict__ st1, int C1, int rows1,
     int groups, double count, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ film, int film_stride, int film_off, float* __restrict__ A,
     float* __restrict__ B, float* __restrict__ bound) {
@@ -202,39 +202,24 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
     const int n = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cbeg = g * cg;
     const bool from0 = cbeg < C0;
-    const float* st = from0 ? st0 : st1;
+    const double* st = from0 ? st0 : st1;
     const int Cs = from0 ? C0 : C1;
     const int rows = from0 ? rows0 : rows1;
     const int cs = from0 ? cbeg : cbeg - C0;
-    // statistics are channel-major [N][C][rows][2]: the group's cg channels x rows partial sums
-    // are ONE contiguous run of cg*rows float2, read with 16-byte loads
+    // statistics are channel-major [N][C][rows][2] fp64: the group's cg channels x rows partial sums
+    // are ONE contiguous, 16-byte aligned run of cg*rows (sum, sum of squares) pairs
     double s1 = 0.0, s2 = 0.0;
     float m2 = 0.0f;                                  // largest sum of squares of any row of the group
-    const size_t items = (size_t)rows * cg;          // float2 count
-    const float* run = st + ((size_t)n * Cs + cs) * rows * 2;
-    if ((reinterpret_cast<uintptr_t>(run) & 15) == 0) {
-        const size_t pairs = items / 2;              // float4 = two (sum, sumsq) entries
-        // unrolled: eight independent 16-byte loads in flight per thread instead of a
-        // load -> convert -> add chain (a 64^3-level group is 64 KB: 16 loads per thread)
+    const size_t items = (size_t)rows * cg;          // double2 count
+    const double2* run = reinterpret_cast<const double2*>(st + ((size_t)n * Cs + cs) * rows * 2);
+    // unrolled: eight independent 16-byte loads in flight per thread instead of a load -> add chain
+    // (a 64^3-level group is 128 KB: 32 loads per thread)
 #pragma unroll 8
-        for (size_t i = threadIdx.x; i < pairs; i += blockDim.x) {
-            const float4 v = *reinterpret_cast<const float4*>(run + i * 4);
-            s1 += (double)v.x + (double)v.z;
-            s2 += (double)v.y + (double)v.w;
-            m2 = fmaxf(m2, fmaxf(v.y, v.w));
-        }
-        if ((items & 1) && threadIdx.x == 0) {
-            s1 += (double)run[(items - 1) * 2];
-            s2 += (double)run[(items - 1) * 2 + 1];
-            m2 = fmaxf(m2, run[(items - 1) * 2 + 1]);
-        }
-    } else {                                         // odd rows x odd channel offset: 8-byte aligned only
-        for (size_t i = threadIdx.x; i < items; i += blockDim.x) {
-            const float2 v = *reinterpret_cast<const float2*>(run + i * 2);
-            s1 += (double)v.x;
-            s2 += (double)v.y;
-            m2 = fmaxf(m2, v.y);
-        }
+    for (size_t i = threadIdx.x; i < items; i += blockDim.x) {
+        const double2 v = run[i];
+        s1 += v.x;
+        s2 += v.y;
+        m2 = fmaxf(m2, (float)v.y);
     }
     __shared__ double red[2][4];
     __shared__ float redm[4], redab[2][4];
@@ -326,7 +311,7 @@ hipError_t ddpm3d_launch_absmax(const float* x0, const float* x1, int N, size_t 
     return hipGetLastError();
 }
 
-hipError_t ddpm3d_launch_gn_finalize(const float* st0, int C0, int rows0, const float* st1, int C1,
+hipError_t ddpm3d_launch_gn_finalize(const double* st0, int C0, int rows0, const double* st1, int C1,
                                      int rows1, int N, int groups, double count, float eps,
                                      const float* gamma, const float* beta, const float* film,
                                      int film_stride, int film_off, float* A, float* B, float* bound,
@@ -342,7 +327,7 @@ hipError_t ddpm3d_launch_gn_finalize(const float* st0, int C0, int rows0, const 
 // channels, 16-byte loads along C.
 #define GN_STATS_VOX 256
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int voxels, int C,
-                                                       int rows, float* __restrict__ stats) {
+                                                       int rows, double* __restrict__ stats) {
     const int n = blockIdx.x / rows, r = blockIdx.x % rows;
     const int v0 = r * GN_STATS_VOX;
     const int v1 = min(v0 + GN_STATS_VOX, voxels);
@@ -350,17 +335,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     // thread -> (channel quad, voxel lane); quads fastest so a wave reads contiguous bytes
     const int qpt = min(C4, 256);
     const int vlanes = 256 / qpt;
-    __shared__ float sh[2][256 * 4];
+    __shared__ double sh[2][256 * 4];
     for (int q0 = 0; q0 < C4; q0 += qpt) {
         const int q = q0 + (threadIdx.x % qpt);
         const int vl = threadIdx.x / qpt;
-        float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+        double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};   // fp64 sums (conv3d_params.h: gn_sums_add)
         if (q < C4 && vl < vlanes) {
             for (int v = v0 + vl; v < v1; v += vlanes) {
                 const float4 t = *reinterpret_cast<const float4*>(x + ((size_t)n * voxels + v) * C + q * 4);
-                s1[0] += t.x; s1[1] += t.y; s1[2] += t.z; s1[3] += t.w;
-                s2[0] = fmaf(t.x, t.x, s2[0]); s2[1] = fmaf(t.y, t.y, s2[1]);
-                s2[2] = fmaf(t.z, t.z, s2[2]); s2[3] = fmaf(t.w, t.w, s2[3]);
+                const double tx = t.x, ty = t.y, tz = t.z, tw = t.w;
+                s1[0] += tx; s1[1] += ty; s1[2] += tz; s1[3] += tw;
+                s2[0] = fma(tx, tx, s2[0]); s2[1] = fma(ty, ty, s2[1]);
+                s2[2] = fma(tz, tz, s2[2]); s2[3] = fma(tw, tw, s2[3]);
             }
         }
 #pragma unroll
@@ -369,12 +355,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         if (threadIdx.x < qpt && q < C4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float a = 0.f, b = 0.f;
+                double a = 0.0, b = 0.0;
                 for (int l = 0; l < vlanes; ++l) {
                     a += sh[0][(l * qpt + threadIdx.x) * 4 + i];
                     b += sh[1][(l * qpt + threadIdx.x) * 4 + i];
                 }
-                float* o = stats + (((size_t)n * C + q * 4 + i) * rows + r) * 2;
+                double* o = stats + (((size_t)n * C + q * 4 + i) * rows + r) * 2;
                 o[0] = a;
                 o[1] = b;
             }
@@ -383,7 +369,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     }
 }
 
-hipError_t ddpm3d_launch_gn_stats(const float* x, int N, int voxels, int C, float* stats, hipStream_t st) {
+hipError_t ddpm3d_launch_gn_stats(const float* x, int N, int voxels, int C, double* stats, hipStream_t st) {
     const int rows = (voxels + GN_STATS_VOX - 1) / GN_STATS_VOX;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(N * rows), dim3(256), 0, st, x, voxels, C, rows, stats);
     return hipGetLastError();

@@ -355,8 +355,8 @@ class _Plan:
             d.out = H.ptr(out.buf)
             if want_stats:
                 out.rows = lib.ddpm3d_conv_stats_rows(N, out.D, out.H, out.W, cin_total, pc.Cout, pc.k)
-                out.stats = torch.empty(N * out.rows * pc.Cout * 2, dtype=torch.float32,
-                                        device=self.eng.device)
+                out.stats = torch.empty(N * out.rows * pc.Cout * 2, dtype=torch.float64,
+                                        device=self.eng.device)     # fp64 (sum, sum of squares) rows
                 self.keep.append(out.stats)    # the descriptor holds a raw pointer
                 d.stats, d.stats_rows = H.ptr(out.stats), out.rows
         else:

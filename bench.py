@@ -14,9 +14,22 @@ inputs resident in HBM.  Ranks work on independent volumes (weak scaling, no
 collective inside a sample; one all_gather of the finished sample per step, as
 scripts/test.py:74-78 does).  Rank 0 prints ONE JSON line.
 
+`--gpus N` with N > 1 and no RANK in the environment starts the N ranks itself
+(a torch.distributed.run child process; this parent never touches a GPU), relays
+rank 0's line and exits with the child's status -- the reference's launcher is one
+command too (test_DDPM_3d_mpi.sh:5).
+
 roofline     : the conv3d implicit-GEMM kernel family (100 % of the path's
                FLOPs).  HIP events around every conv launch of one UNet
                forward per timed step; achieved = algorithmic FLOPs / event time.
+               device_sustained_tflops = what THIS board's matrix pipes sustain in a
+               register-only MFMA loop of the instruction the dominant kernel issues
+               (ddpm3d_mfma_probe, ~50 ms, outside the timed region): boards of one
+               pool differ by several per cent, frac_of_sustained does not.
+parity       : the metric's "PSNR vs ref".  (a) the first timed volume against the same
+               volume (same noise) in the exact-fp32 arithmetic of this library, all 250
+               steps; (b) the first `--cpu-steps`+1 reverse steps against the CPU oracle
+               (oracle/, pinned to the reference's own outputs) on the same injected noise.
 cpu_baseline : oracle/ (the CPU restatement pinned to the reference) timed on
                this box's host cores on a bounded sample (a few p_sample steps
                of the same workload), extrapolated to volumes/s.  N=1, rank 0.
@@ -26,6 +39,8 @@ import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -102,8 +117,49 @@ def build_model(arch, respacing, device):
     return model, diff, sd
 
 
+def host_cpu():
+    """(model string, physical cores, cores this process may run on) of the host."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name" and model == "unknown":
+                    model = v
+                elif k == "physical id":
+                    pid = v
+                elif k == "core id":
+                    cid = v
+                elif not k and pid is not None:
+                    phys.add((pid, cid))
+                    pid = cid = None
+        if pid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count() or 1
+    return model, (len(phys) or (os.cpu_count() or 1)), aff
+
+
+def psnr_db(got, ref):
+    """10 log10(range^2 / MSE), range = max - min of the reference volume."""
+    mse = float(((got.double() - ref.double()) ** 2).mean())
+    rng = float(ref.max() - ref.min())
+    return float("inf") if mse == 0 else 10.0 * float(np.log10(rng * rng / mse))
+
+
+def rel_err(got, ref):
+    return float((got.double() - ref.double()).abs().max() / ref.double().abs().max())
+
+
 def cpu_baseline(arch, sd, size, respacing, n_steps, threads):
-    """Time the oracle's p_sample steps on the host cores (bounded sample)."""
+    """Time the oracle's p_sample steps on the host cores (bounded sample).  Returns the record
+    and the oracle's state after those steps (the checker of parity (b))."""
     from guided_diffusion import synth
     from oracle import sampler_ref, schedule_ref, unet_ref
     torch.set_num_threads(threads)
@@ -125,14 +181,18 @@ def cpu_baseline(arch, sd, size, respacing, n_steps, threads):
             times.append(time.time() - t0)
             log("[bench] cpu oracle step %d: %.2fs" % (k, times[-1]))
     per_step = float(np.mean(times[1:]))
+    cpu_model, phys, aff = host_cpu()
     return {
         "value": 1.0 / (per_step * T),
         "unit": "volumes/s",
         "cores": threads,
+        "cpu_model": cpu_model,
+        "physical_cores": phys,
+        "cores_available": aff,
         "kind": "port",
         "sample": "%d p_sample steps (after 1 warm-up) of the same 1x%d^3 published-arch workload, "
                   "%.2f s/step, extrapolated x%d steps" % (n_steps, size, per_step, T),
-    }
+    }, img
 
 
 def main():
@@ -145,9 +205,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
     ap.add_argument("--arch", choices=["published", "tiny"], default="published")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps for cpu_baseline (0 = skip)")
-    ap.add_argument("--f32-steps", type=int, default=25,
-                    help="DDPM steps of the same workload timed in the exact-fp32 arithmetic for the "
-                         "exact_f32 sub-record (0 = skip; only with the default f16x3 precision)")
+    ap.add_argument("--f32-steps", type=int, default=-1,
+                    help="DDPM steps of the first timed volume repeated in the exact-fp32 arithmetic "
+                         "(exact_f32 sub-record and parity (a)); -1 = all of them, 0 = skip; only "
+                         "with the default f16x3 precision")
+    ap.add_argument("--probe-ms", type=float, default=50.0,
+                    help="length of the MFMA calibration loop (roofline.device_sustained_tflops; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for cpu_baseline")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -161,6 +224,25 @@ def main():
     ap.add_argument("--sampler", choices=["ddpm", "ddim"], default="ddpm",
                     help="ddim: --ddpm-steps DDIM steps (timestep_respacing ddimN, eta 0)")
     args = ap.parse_args()
+
+    # `bench.py --gpus N` by itself: start the N ranks as a CHILD process (this parent has made no
+    # GPU call and never makes one), relay rank 0's JSON line, exit with the child's status.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("[bench] starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+        child = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+        lines = [ln for ln in child.stdout.decode().splitlines() if ln.startswith("{")]
+        if child.returncode == 0 and len(lines) != 1:
+            log("[bench] expected one JSON line from rank 0, got %d" % len(lines))
+            sys.exit(1)
+        for ln in lines:
+            print(ln, flush=True)
+        sys.exit(child.returncode)
 
     # stdout carries exactly ONE JSON line.  Libraries (RCCL prints a version banner) write to
     # fd 1 directly, so fd 1 is pointed at stderr for the run and the result goes to the saved fd.
@@ -187,7 +269,16 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     if args.gpus != world:
-        log("[bench] note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world))
+        raise SystemExit("[bench] --gpus %d but WORLD_SIZE %d: launch one rank per GPU (plain "
+                         "`python bench.py --gpus N` starts them itself)" % (args.gpus, world))
+    rccl_ranks = 1
+    if use_dist:
+        # the number of ranks the collective library itself sees: one all_gather of the rank ids
+        ids = [torch.zeros(1, dtype=torch.int64, device=torch.device("cpu") if gloo else torch.device("cuda", dev_index))
+               for _ in range(world)]
+        dist.all_gather(ids, torch.full((1,), rank, dtype=torch.int64, device=ids[0].device))
+        assert sorted(int(t.item()) for t in ids) == list(range(world))
+        rccl_ranks = dist.get_world_size()
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
     coll_dev = torch.device("cpu") if gloo else device
@@ -222,7 +313,9 @@ def main():
         overrides += " (%d attention blocks)" % n_attn
     T = diff.num_timesteps
 
-    def one_volume(step_index, measure):
+    loop = diff.ddim_sample_loop_progressive if args.sampler == "ddim" else diff.p_sample_loop_progressive
+
+    def one_volume(step_index, measure, max_steps=None):
         # per-volume noise keyed by the GLOBAL volume index, so results do not depend on world size
         gen = torch.Generator(device=device)
         gen.manual_seed(10 + step_index * world + rank)
@@ -231,12 +324,15 @@ def main():
         timing = []
         k = 0
         final = None
-        loop = diff.ddim_sample_loop_progressive if args.sampler == "ddim" else diff.p_sample_loop_progressive
         for final in loop(model, shape, noise, model_kwargs={"low_res": lr}):
             k += 1
             plan.timing = timing if (measure and k == T // 2) else None   # instrument ONE forward
+            if max_steps is not None and k >= max_steps:
+                break
         plan.timing = None
         sample = final["sample"]
+        if max_steps is not None:
+            return sample, timing
         if use_dist:
             mine = sample.to(coll_dev)
             gathered = [torch.empty_like(mine) for _ in range(world)]
@@ -255,10 +351,13 @@ def main():
         log("[bench] rank %d warm-up volume %d: %.2fs" % (rank, w, time.time() - t0))
 
     timings = []
+    first_sample = None
     sync()
     t_start = time.time()
     for s in range(args.steps):
         sample, tm = one_volume(s, True)
+        if s == 0:
+            first_sample = sample.clone()
         timings += tm
         if rank == 0:
             torch.cuda.synchronize()
@@ -318,38 +417,77 @@ def main():
                                "ms": round(a[2] / max(1, args.steps), 3)} for t, a in sorted(by_tag.items())},
         }
 
-    # the same workload in the EXACT fp32 arithmetic (v_mfma_f32_32x32x2_f32), a bounded number of
-    # steps: the driver-timed record then carries an exact-arithmetic number beside the default one
+    # MFMA calibration of this board (outside the timed region): the instruction the dominant kernel
+    # issues, two waves per SIMD like that kernel, register-only, ~50 ms
+    from guided_diffusion import _hip as HH
+    sustained = None
+    if roof is not None and args.probe_ms > 0 and rank == 0:
+        lib = HH.load()
+        kind = {"f32": HH.PROBE_F32_32X32X2, "bf16": HH.PROBE_BF16_32X32X16}.get(args.precision, HH.PROBE_F16_32X32X16)
+        cus = torch.cuda.get_device_properties(device).multi_processor_count
+        blocks = 2 * cus
+        pout = torch.empty(blocks * 256, dtype=torch.float32, device=device)
+        pclk = torch.zeros(blocks * 2, dtype=torch.int64, device=device)
+        st = HH.stream()
+        fl_iter = lib.ddpm3d_mfma_probe_flops_per_iter(kind)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters, ms = 4000, 0.0
+        for attempt in range(3):   # warm launch, sizing launch, the timed one
+            e0.record()
+            HH.check(lib.ddpm3d_mfma_probe(kind, iters, blocks, HH.ptr(pout), HH.ptr(pclk), st))
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            if attempt == 1:
+                iters = max(1000, int(iters * args.probe_ms / max(ms, 1e-3)))
+        c = pclk.view(blocks, 2).double().cpu()
+        sustained = {"tflops": fl_iter * iters * blocks / (ms * 1e-3) / 1e12,
+                     "ghz": float((c[:, 0] / c[:, 1]).median()) * 0.1, "ms": ms}
+        mfma_per_product = (PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS) / roof["peak"]
+        roof["device_sustained_tflops"] = round(sustained["tflops"], 1)
+        roof["device_sustained_clock_ghz"] = round(sustained["ghz"], 3)
+        roof["device_sustained_basis"] = ("ddpm3d_mfma_probe: register-only loop of the dominant kernel's MFMA "
+                                          "instruction, 2 waves/SIMD on every CU, pseudo-random operands, "
+                                          "%.0f ms, run after the timed region" % ms)
+        roof["frac_of_sustained"] = round(roof["achieved"] * mfma_per_product / sustained["tflops"], 4)
+        log("[bench] device sustains %.0f TFLOP/s of MFMA issue at %.2f GHz; dominant kernel at %.3f of it"
+            % (sustained["tflops"], sustained["ghz"], roof["frac_of_sustained"]))
+
+    # The first timed volume again (same noise, same per-step draws) in the EXACT fp32 arithmetic
+    # (v_mfma_f32_32x32x2_f32): the driver-timed record then carries an exact-arithmetic number beside
+    # the default one, and -- over all T steps -- the parity of the default arithmetic against it.
     exact = None
-    if args.precision == "f16x3" and args.f32_steps > 0 and rank == 0 and world == 1:
+    parity = {}
+    if args.precision == "f16x3" and args.f32_steps != 0 and rank == 0 and world == 1:
         model.conv_precision = "f32"
         eng32 = model.engine()
-        k_steps = min(args.f32_steps, T)
-        gen = torch.Generator(device=device)
-        gen.manual_seed(77)
-        noise = torch.randn(*shape, device=device, generator=gen)
-        loop = diff.ddim_sample_loop_progressive if args.sampler == "ddim" else diff.p_sample_loop_progressive
-
-        def run_steps(n):
-            for k, _ in enumerate(loop(model, shape, noise, model_kwargs={"low_res": lr})):
-                if k + 1 >= n:
-                    break
-        run_steps(2)
+        k_steps = T if args.f32_steps < 0 else min(args.f32_steps, T)
+        plan_default, plan = plan, eng32.plan(B, S, S, S)
+        one_volume(0, False, max_steps=2)          # warm-up: plan, weight packing
         torch.cuda.synchronize()
         t0 = time.time()
-        run_steps(k_steps)
+        sample32, _ = one_volume(0, False, max_steps=k_steps)
         torch.cuda.synchronize()
         dt = time.time() - t0
-        fl32 = sum(f for _, f in eng32.plan(B, S, S, S).conv_meta.values())
+        fl32 = sum(f for _, f in plan.conv_meta.values())
+        plan = plan_default
         tf = fl32 * k_steps / dt / 1e12
         exact = {"precision": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)", "steps_timed": k_steps,
                  "ms_per_ddpm_step": round(1000.0 * dt / k_steps, 3),
-                 "value": B / (dt / k_steps * T), "unit": "volumes/s (extrapolated to %d steps)" % T,
+                 "value": B / (dt / k_steps * T), "unit": "volumes/s" + ("" if k_steps == T else
+                                                                        " (extrapolated to %d steps)" % T),
                  "tflops": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                  "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
                  "note": "whole step (all kernels), wall clock; conv FLOPs only"}
         model.conv_precision = args.precision
         log("[bench] exact fp32 arithmetic: %d steps in %.2fs (%.1f TFLOP/s)" % (k_steps, dt, tf))
+        if k_steps == T and first_sample is not None:
+            parity["vs_exact_f32"] = {
+                "what": "first timed volume (all %d steps) vs the same volume, same noise, in this library's "
+                        "exact-fp32 arithmetic" % T,
+                "rel_err": rel_err(first_sample, sample32), "psnr_db": round(psnr_db(first_sample, sample32), 2)}
+            log("[bench] parity vs exact f32: rel %.2e, PSNR %.1f dB"
+                % (parity["vs_exact_f32"]["rel_err"], parity["vs_exact_f32"]["psnr_db"]))
 
     if rank == 0:
         vols = args.steps * B * world
@@ -379,8 +517,10 @@ def main():
                        "parallelism": "independent volumes per rank (dp%d), all_gather of finished samples" % world,
                        "tflop_per_volume": round(flops_fwd * T / B / 1e12, 1),
                        "conv_arithmetic": ARITH[args.precision][1]},
+            "rccl_ranks": rccl_ranks,
             "roofline": roof,
             "exact_f32": exact,
+            "parity": parity or None,
         }
         if world == 1 and args.cpu_steps > 0:
             threads = os.cpu_count() or 1
@@ -392,7 +532,25 @@ def main():
             # threads than that only thrash (measured: 87 s/step at 256 threads)
             threads = min(threads, args.cpu_threads)
             sd_cpu = {k: v for k, v in sd.items()}
-            res["cpu_baseline"] = cpu_baseline(arch, sd_cpu, S, respacing, args.cpu_steps, threads)
+            res["cpu_baseline"], cpu_img = cpu_baseline(arch, sd_cpu, S, respacing, args.cpu_steps, threads)
+            # parity (b): the same first reverse steps on the GPU, the oracle's noise injected
+            n_or = args.cpu_steps + 1
+            draws = [torch.from_numpy(a).to(device) for a in synth.synth_noise((1, 1, S, S, S), n_or + 1, seed=10)]
+            lr1 = torch.from_numpy(synth.synth_low_res((1, 1, S, S, S), seed=1234)).to(device)
+            fin = None
+            for k, fin in enumerate(diff.p_sample_loop_progressive(model, (1, 1, S, S, S), draws[0],
+                                                                   model_kwargs={"low_res": lr1},
+                                                                   step_noise=draws[1:] + [draws[1]] * T)):
+                if k + 1 >= n_or:
+                    break
+            got = fin["sample"].cpu()
+            res["parity"] = dict(res["parity"] or {})
+            res["parity"]["vs_cpu_oracle"] = {
+                "what": "state after the first %d reverse steps (injected noise) vs oracle/ on the host, "
+                        "which is pinned to the reference's own outputs (tests/golden)" % n_or,
+                "rel_err": rel_err(got, cpu_img), "psnr_db": round(psnr_db(got, cpu_img), 2)}
+            log("[bench] parity vs CPU oracle after %d steps: rel %.2e, PSNR %.1f dB"
+                % (n_or, res["parity"]["vs_cpu_oracle"]["rel_err"], res["parity"]["vs_cpu_oracle"]["psnr_db"]))
         else:
             res["cpu_baseline"] = None
         sys.stdout.flush()

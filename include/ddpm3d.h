@@ -24,8 +24,10 @@
  *     (ddpm3d_ncdhw_to_ndhwc / the planar input mode of the first conv /
  *     the NCDHW store mode of the last conv).
  *   - GroupNorm is never a pass of its own: every conv epilogue emits
- *     per-(sample, row-tile, channel) partial sums (sum, sum of squares) of
- *     what it stores; ddpm3d_gn_finalize folds them (fp64) into per-(n, c)
+ *     per-(sample, row-tile, channel) partial sums (sum, sum of squares;
+ *     accumulated and stored in fp64, so that the variance survives a mean
+ *     hundreds of standard deviations large) of what it stores;
+ *     ddpm3d_gn_finalize folds them (fp64) into per-(n, c)
  *     affine coefficients A, B; the NEXT conv applies
  *     y = SiLU(A*x + B) while it stages its input tile into LDS.
  */
@@ -113,7 +115,8 @@ typedef struct ddpm3d_conv_desc {
     float* out;
     int32_t out_layout;     /* DDPM3D_OUT_*                                          */
     int32_t stats_rows;     /* rows per sample of `stats` (from ddpm3d_conv_stats_rows) */
-    float* stats;           /* [N][Cout][stats_rows][2] (channel-major) or NULL      */
+    double* stats;          /* [N][Cout][stats_rows][2] fp64 (sum, sum of squares), channel-major,
+                               16-byte aligned, or NULL                               */
     /* scratch for split-K partial sums (low-resolution levels, where the voxel
      * tiles alone cannot fill 256 CUs); >= ddpm3d_conv_workspace_bytes(...) bytes,
      * may be shared by all convs of a stream, NULL when that query returns 0 */
@@ -215,8 +218,8 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* desc, void* stream);
  * film = [N][film_stride] rows holding scale at [film_off, +C) and shift at
  * [film_off + C, +C); NULL -> no FiLM.
  */
-int ddpm3d_gn_finalize(const float* stats0, int C0, int rows0,
-                       const float* stats1, int C1, int rows1,
+int ddpm3d_gn_finalize(const double* stats0, int C0, int rows0,
+                       const double* stats1, int C1, int rows1,
                        int N, int groups, double count, float eps,
                        const float* gamma, const float* beta,
                        const float* film, int film_stride, int film_off,
@@ -237,7 +240,7 @@ int ddpm3d_absmax(const float* x0, const float* x1, int N, size_t per_sample, fl
 /* partial sums of an NDHWC tensor that no conv epilogue produced;
  * stats [N][C][rows][2] with rows = ddpm3d_gn_stats_rows(voxels) */
 int ddpm3d_gn_stats_rows(int voxels);
-int ddpm3d_gn_stats(const float* x, int N, int voxels, int C, float* stats, void* stream);
+int ddpm3d_gn_stats(const float* x, int N, int voxels, int C, double* stats, void* stream);
 
 /* nn.py:103-121 timestep_embedding: out[r] = [cos(t_r f) | sin(t_r f)] (+0 pad).
  * freqs = [dim/2] fp32 table.  The reference evaluates

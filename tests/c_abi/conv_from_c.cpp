@@ -48,7 +48,8 @@ int main(void) {
             ref[v * Co + co] = (float)acc + res[v * Co + co];
         }
 
-    float *dx, *dw, *db, *dA, *dB, *dres, *dout, *dstats, *dbound;
+    float *dx, *dw, *db, *dA, *dB, *dres, *dout, *dbound;
+    double* dstats;   /* GroupNorm partial sums are fp64 */
     CHECK_HIP(hipMalloc(&dx, sizeof(float) * vox * Ci));
     CHECK_HIP(hipMalloc(&dw, sizeof(float) * Co * Ci * 27));
     CHECK_HIP(hipMalloc(&db, sizeof(float) * Co));
@@ -65,7 +66,7 @@ int main(void) {
     CHECK_HIP(hipMemcpy(dres, res, sizeof(float) * vox * Co, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(dbound, &amax, sizeof(float), hipMemcpyHostToDevice));   /* upper bound of |act| */
     const int rows = ddpm3d_conv_stats_rows(N, D, H, W, Ci, Co, 3);
-    CHECK_HIP(hipMalloc(&dstats, sizeof(float) * Co * rows * 2));
+    CHECK_HIP(hipMalloc(&dstats, sizeof(double) * Co * rows * 2));
     const size_t ws_bytes = ddpm3d_conv_workspace_bytes(N, D, H, W, Ci, Co, 3);
     void* dws = NULL;
     if (ws_bytes) CHECK_HIP(hipMalloc(&dws, ws_bytes));
@@ -91,8 +92,8 @@ int main(void) {
         CHECK_HIP(hipMemcpy(got, dout, sizeof(float) * vox * Co, hipMemcpyDeviceToHost));
         double err = 0.0, mag = 0.0;
         for (int i = 0; i < vox * Co; ++i) { err = fmax(err, fabs((double)got[i] - ref[i])); mag = fmax(mag, fabs((double)ref[i])); }
-        float* stats = (float*)malloc(sizeof(float) * Co * rows * 2);
-        CHECK_HIP(hipMemcpy(stats, dstats, sizeof(float) * Co * rows * 2, hipMemcpyDeviceToHost));
+        double* stats = (double*)malloc(sizeof(double) * Co * rows * 2);
+        CHECK_HIP(hipMemcpy(stats, dstats, sizeof(double) * Co * rows * 2, hipMemcpyDeviceToHost));
         double s1 = 0.0, r1 = 0.0;
         for (int r = 0; r < rows; ++r) s1 += stats[(0 * rows + r) * 2];          /* channel 0: sum over the volume */
         for (int v = 0; v < vox; ++v) r1 += ref[v * Co];

@@ -91,7 +91,7 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
         d.workspace, d.workspace_bytes = H.ptr(ws), need
     stats = None
     if want_stats and out_layout == H.OUT_NDHWC:
-        stats = torch.full((N, co, rows, 2), float("nan"), dtype=torch.float32, device=dev)
+        stats = torch.full((N, co, rows, 2), float("nan"), dtype=torch.float64, device=dev)
         d.stats, d.stats_rows = H.ptr(stats), rows
     H.check(lib.ddpm3d_conv3d(C.byref(d), H.stream()))
     torch.cuda.synchronize()
@@ -124,7 +124,7 @@ def gn_stats(x_ndhwc):
     Cn = x_ndhwc.shape[-1]
     vox = x_ndhwc[0].numel() // Cn
     rows = lib.ddpm3d_gn_stats_rows(vox)
-    st = torch.full((N, Cn, rows, 2), float("nan"), dtype=torch.float32, device=x_ndhwc.device)
+    st = torch.full((N, Cn, rows, 2), float("nan"), dtype=torch.float64, device=x_ndhwc.device)
     H.check(lib.ddpm3d_gn_stats(H.ptr(x_ndhwc), N, vox, Cn, H.ptr(st), H.stream()))
     torch.cuda.synchronize()
     return st

@@ -249,6 +249,34 @@ def test_full_size_forward_properties():
     assert rel_err(y_def, y_exact) < 1e-4
 
 
+def test_full_size_forward_vs_cpu_oracle():
+    """full-size parity must not rest on self-comparison.  ONE published-architecture
+    forward at BASELINE config 2's size (1 x 64^3; 5 831 GFLOP, a few seconds of host time) through the
+    CPU oracle -- which is pinned to the reference's own outputs (tests/test_oracle_golden.py) --
+    against the GPU in BOTH arithmetics, per output channel (the eps and the variance channel each on
+    its own scale) at the single-forward bar.  Covers what only appears above 32-wide grids: second
+    z-tile rows, XCD orders with > 2048 workgroups, offsets beyond 2^31 bits."""
+    from oracle import unet_ref
+    shape = (1, 1, 64, 64, 64)
+    x, lr = inputs(shape)
+    t = torch.tensor([617])
+    model, _ = build(PUBLISHED)
+    assert model.conv_precision == "f16x3"
+    cfg = unet_ref.sr_config(**PUBLISHED)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, cfg, x, t, lr).numpy()
+        y = model(x.cuda(), t.cuda(), low_res=lr.cuda()).cpu().numpy()
+    assert rel_err_per_channel(y, ref) < 1e-4
+    del model
+    torch.cuda.empty_cache()
+    exact, _ = build(PUBLISHED, precision="f32")
+    with torch.no_grad():
+        y32 = exact(x.cuda(), t.cuda(), low_res=lr.cuda()).cpu().numpy()
+    assert rel_err_per_channel(y32, ref) < 1e-4
+
+
 def test_batch_beyond_32bit_addressing_is_split():
     """One launch addresses a tensor with 32-bit byte offsets (the C ABI refuses more: "split the
     batch").  The engine does the splitting: 130 volumes of 64^3 through the tiny net make 4.4 GB

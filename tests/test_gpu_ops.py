@@ -336,6 +336,44 @@ def test_groupnorm_film(hc):
     assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("ratio", [30.0, 300.0])
+def test_groupnorm_with_large_mean(hc, ratio):
+    """un-normalised PET counts (scripts/test.py:201-203 feeds them raw) put tensors
+    whose |mean| is tens to hundreds of standard deviations in front of a GroupNorm.  With fp32 partial
+    sums E[x^2] - mean^2 loses ratio^2 x 1e-7 of the variance to cancellation (1e-2 at ratio 300); the
+    partial sums are fp64 (conv3d_params.h: gn_sums_add).  Both producers of statistics -- the
+    stand-alone pass and a conv epilogue -- then finalize -> the next conv's prologue, against
+    group_norm evaluated in fp64 (nn.py:93-100), at the 1e-4 bar on the NORMALISED output's scale."""
+    import guided_diffusion._hip as H
+    C = 64
+    gamma, beta = 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    # (a) stand-alone statistics: per-group offsets of +-ratio standard deviations
+    x = rnd(2, C, 3, 8, 8, seed=1)
+    off = (ratio * torch.sign(rnd(2, 32, seed=7)))[:, :, None].expand(2, 32, C // 32).reshape(2, C)
+    x = x + off[:, :, None, None, None]
+    ref = F.silu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)).float()
+    A, B = _gn_affine(hc, [x], gamma, beta)
+    w = torch.eye(C).reshape(C, C, 1, 1, 1).contiguous()
+    out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), torch.zeros(C).cuda(), (3, 8, 8),
+                          aff=(A, B), act=H.ACT_SILU)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < 1e-4
+    # (b) statistics from a conv epilogue whose output carries the offset (a large bias), in the exact
+    # and the default arithmetic, direct and Winograd-D kernels
+    for co, precision in ((64, 0), (64, 1), (128, 3)):
+        xi = rnd(1, 32, 6, 16, 16, seed=11)
+        wc = rnd(co, 32, 3, 3, 3, seed=12, scale=0.05)
+        y0 = F.conv3d(xi, wc, None, padding=1)
+        g = y0.reshape(1, 32, -1)
+        bias = (ratio * g.std(dim=2)[0] * torch.sign(rnd(32, seed=13)))[:, None].expand(32, co // 32).reshape(co)
+        gm, bt = 1 + 0.1 * rnd(co, seed=14), 0.1 * rnd(co, seed=15)
+        out, stats, _ = hc.conv3d([hc.to_ndhwc(xi).cuda()], wc.cuda(), bias.cuda(), (6, 16, 16), precision=precision)
+        y = hc.to_ncdhw(out.cpu())
+        refn = F.group_norm(y.double(), 32, gm.double(), bt.double(), 1e-5)
+        A, B = hc.gn_finalize([stats], 6 * 16 * 16, gm.cuda(), bt.cuda())
+        got = y.double() * A.cpu().double()[:, :, None, None, None] + B.cpu().double()[:, :, None, None, None]
+        assert rel_err(got.numpy(), refn.numpy()) < 1e-4, (ratio, precision)
+
+
 def test_conv_stats_feed_groupnorm(hc):
     """Statistics from a conv epilogue, folded, reproduce group_norm of its output."""
     x = rnd(1, 32, 5, 12, 12, seed=1)
@@ -575,7 +613,7 @@ def test_strided_downsample_conv_as_conv_plus_subsample(hc):
     H.check(lib.ddpm3d_subsample_hw2(H.ptr(full), N, D, Hh, W, co, H.ptr(out), H.stream()))
     vox = D * (Hh // 2) * (W // 2)
     rows = lib.ddpm3d_gn_stats_rows(vox)
-    stats = torch.zeros(N, co, rows, 2, dtype=torch.float32, device="cuda")
+    stats = torch.zeros(N, co, rows, 2, dtype=torch.float64, device="cuda")
     H.check(lib.ddpm3d_gn_stats(H.ptr(out), N, vox, co, H.ptr(stats), H.stream()))
     torch.cuda.synchronize()
     assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL

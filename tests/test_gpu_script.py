@@ -110,6 +110,33 @@ def test_two_rank_run_equals_one_rank_and_loads_checkpoint(tmp_path):
     assert not np.array_equal(a, c)
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the reference's launcher is
+    one command, test_DDPM_3d_mpi.sh:5): the parent starts a two-rank torch.distributed.run child,
+    relays rank 0's ONE JSON line and its exit status.  Rehearsal on the one-GPU box: gloo, both ranks
+    on cuda:0, tiny network, 5 DDPM steps."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo",
+           "--steps", "1", "--warmup", "0", "--ddpm-steps", "5", "--arch", "tiny", "--size", "16",
+           "--cpu-steps", "0", "--probe-ms", "5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["scaling"] == "weak"
+    assert rec["steps"] == 1 and rec["value"] > 0
+    # a launcher that hands over the wrong world size is refused, not silently accepted
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"],
+                         env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True,
+                         timeout=600)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
 def test_c_abi_from_plain_cpp(tmp_path):
     """The boundary is a C ABI, not a Python extension: tests/c_abi/conv_from_c.cpp (no Python, no torch:
     hipMalloc'd buffers, `ddpm3d.h`, -lddpm3d) packs weights and runs one fused conv in the exact and the

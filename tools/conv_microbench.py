@@ -48,7 +48,7 @@ def main():
     H.check(lib.ddpm3d_pack_conv_weight(H.ptr(w), a.cout, a.cin, a.k, a.precision, H.ptr(wp), H.stream()))
     out = torch.empty(N, D, Hh, W, a.cout, device=dev)
     rows = lib.ddpm3d_conv_stats_rows(N, D, Hh, W, a.cin, a.cout, a.k)
-    stats = torch.empty(N, a.cout, rows, 2, device=dev)
+    stats = torch.empty(N, a.cout, rows, 2, dtype=torch.float64, device=dev)
     need = lib.ddpm3d_conv_workspace_bytes(N, D, Hh, W, a.cin, a.cout, a.k)
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
     d = H.ConvDesc()
