@@ -494,10 +494,19 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     else if (c.PREC == DDPM3D_PREC_BF16_WZ)
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_BF16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
-    else if (k.CoutPad % 384 != 0)
-        hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 1>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
-    else
-        hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16X3>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
+    else {
+        // kernel_hint bits 12..14: force an issue order (A/B measurements; identical arithmetic), 0 = by shape
+        int order = (k.hint & DDPM3D_HINT_WZ_ORDER_MASK) >> DDPM3D_HINT_WZ_ORDER_SHIFT;
+        if (order == 0) order = k.CoutPad % 384 != 0 ? 2 : 1;   // (value = IL + 1)
+        switch (order - 1) {
+            case 0: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 0>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
+            case 1: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 1>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
+            case 2: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 2>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
+            case 3: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 3>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
+            case 4: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
+            default: return hipErrorInvalidValue;
+        }
+    }
     return hipGetLastError();
 }
 #else   // the direct kernels of one arithmetic mode

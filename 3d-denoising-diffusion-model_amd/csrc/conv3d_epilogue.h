@@ -27,6 +27,33 @@ struct LdsGeom {
     static constexpr int RZ = TX == 8 ? HY * RY : pad_to_residue(HY * RY, 0);
 };
 
+
+// ---- 4x4 transpose of four registers across the four lanes of a quad (lanes 4q .. 4q+3):
+// new a_r(lane l) = old a_l(lane r).  Two butterfly stages of DPP quad permutes; b0 / b1 = bit 0 / 1
+// of the lane id.  Used by the epilogue: a lane's four consecutive accumulator registers are four
+// consecutive x voxels of ONE cout; after the transpose the lane holds four consecutive COUTS of one
+// voxel, i.e. one 16-byte store instead of four 4-byte ones.
+__device__ __forceinline__ float quad_xchg1(float v) {   // lane ^ 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_xchg2(float v) {   // lane ^ 2
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void quad_transpose(float (&a)[4], bool b0, bool b1) {
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {          // pairs (0,1), (2,3) across lane bit 0
+        const float y = quad_xchg1(b0 ? a[k] : a[k + 1]);
+        a[k] = b0 ? y : a[k];
+        a[k + 1] = b0 ? a[k + 1] : y;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {             // pairs (0,2), (1,3) across lane bit 1
+        const float y = quad_xchg2(b1 ? a[k] : a[k + 2]);
+        a[k] = b1 ? y : a[k];
+        a[k + 2] = b1 ? a[k + 2] : y;
+    }
+}
+
 // Epilogue shared by the conv kernels: bias / residual / store / GroupNorm partial sums, or
 // the raw split-K slab.  C/D map of a 32x32 MFMA: col = lane&31 (cout),
 // row = (reg&3) + 8*(reg>>2) + 4*half.
@@ -94,6 +121,81 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 if (r16) return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rrsrc, roff_, so, 0) << 16);
                 return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff_, so, 0));
             };
+            // ---- WIDE form (r03): residual none / same and Cout % 4 == 0 -- every such launch of the network.
+            // Phase stamps of the dominant kernel (profiles/r03_wz_stamps_*.txt) put its epilogue at 8 % of a
+            // wave's life without a residual and 11.5 % with one: 64 four-byte stores (+ 64 four-byte loads) per
+            // lane, bound by the CU's store ISSUE rate (~7 B/clk/CU), not by bandwidth.  A lane's registers
+            // 4g .. 4g+3 are four consecutive x voxels of its cout; transposed across the lane quad it holds
+            // four consecutive couts of ONE voxel: 16 stores of 16 bytes (one wave instruction = 8 voxels x
+            // 128 contiguous bytes), the residual read the same way.  The statistics are taken in the
+            // transposed layout (after the residual add) and folded over the quad and the two halves.
+            if ((rm == DDPM3D_RES_NONE || rm == DDPM3D_RES_SAME) && (p.Cout & 3) == 0) {
+                const int li = threadIdx.x & 3;
+                const bool b0 = (li & 1) != 0, b1 = (li & 2) != 0;
+                const unsigned lane_vox = (((unsigned)z0 * p.H + y0 + hy) * p.W + x0 + hx + li);
+                const unsigned cq = (unsigned)(cout & ~3);
+                const unsigned wv = cvalid ? lane_vox * cstride + cq * eso : DDPM3D_OOB_OFFSET;
+                const unsigned wr = cvalid ? lane_vox * rstride + cq * esr : DDPM3D_OOB_OFFSET;
+                const float bias_w = (!split && cvalid) ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
+                double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    f32x4 rq[4];
+                    if (resid) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int m0 = (wm * MT + t) * 32 + 8 * g;
+                            const int ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL), tx = m0 & (TX - 1);
+                            const unsigned so = (unsigned)((tz * p.H + ty) * p.W + tx) * rstride;
+                            if (r16) rq[g] = bf16x4_expand(__builtin_amdgcn_raw_buffer_load_b64(rrsrc, wr, so, 0));
+                            else rq[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, wr, so, 0));
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float a[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = PREC != 0 ? acc[t][4 * g + i] * oscale : acc[t][4 * g + i];
+                            a[i] = split ? v : v + bias_w;
+                        }
+                        quad_transpose(a, b0, b1);
+                        if (!split) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (resid) a[i] += rq[g][i];
+                                if (p.stats != nullptr) gn_sums_add(d1[i], d2[i], a[i]);
+                            }
+                        }
+                        const int m0 = (wm * MT + t) * 32 + 8 * g;
+                        const int ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL), tx = m0 & (TX - 1);
+                        const unsigned so = (unsigned)((tz * p.H + ty) * p.W + tx) * cstride;
+                        if (o16)
+                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{bf16_pack(a[0], a[1]), bf16_pack(a[2], a[3])}, drsrc, wv, so, 0);
+                        else
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]),
+                                                                         __builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])},
+                                                                   drsrc, wv, so, 0);
+                    }
+                }
+                if (!split && p.stats != nullptr) {
+                    // fold the quad's four voxel lanes and the two halves; then lane li keeps cout cq + li = its own
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        d1[i] += __shfl_xor(d1[i], 1); d2[i] += __shfl_xor(d2[i], 1);
+                        d1[i] += __shfl_xor(d1[i], 2); d2[i] += __shfl_xor(d2[i], 2);
+                        d1[i] += __shfl_xor(d1[i], 32); d2[i] += __shfl_xor(d2[i], 32);
+                    }
+                    const double s1 = b1 ? (b0 ? d1[3] : d1[2]) : (b0 ? d1[1] : d1[0]);
+                    const double s2 = b1 ? (b0 ? d2[3] : d2[2]) : (b0 ? d2[1] : d2[0]);
+                    if (half == 0 && cvalid) {
+                        const size_t row = (size_t)tile_in_n * WM + wm;
+                        *reinterpret_cast<double2*>(p.stats + (((size_t)n * p.Cout + cout) * p.stats_rows + row) * 2) =
+                            make_double2(s1, s2);
+                    }
+                }
+                return;
+            }
             roff_ = cvalid ? rbase : DDPM3D_OOB_OFFSET;
             const float bias = (!split && cvalid) ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
             double s1 = 0.0, s2 = 0.0;   // GroupNorm partial sums in fp64 (gn_sums_add below)

@@ -191,8 +191,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ------------------------------------------------------------- GN finalize
 // One workgroup per (n, group): fold partial (sum, sumsq) rows in fp64, then
-// write A, B for the group's channels.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(
+// write A, B for the group's channels.  256 threads, or 1024 where a group's run of partial sums
+// is long (the launcher decides from the shape alone, so results stay repeatable): the kernel is a
+// latency chain -- N x 32 workgroups on 256 CUs, each waiting for its own loads -- and four times
+// the loads in flight cut the long ones (2048 rows at the 64^3 level: 128 KB per group) from
+// 17-33 us to the launch floor (r03: the fp64 statistics had doubled this kernel's bytes).
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(
     const double* __restrict__ st0, int C0, int rows0, const double* __restrict__ st1, int C1, int rows1,
     int groups, double count, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ film, int film_stride, int film_off, float* __restrict__ A,
@@ -221,19 +225,23 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
         s2 += v.y;
         m2 = fmaxf(m2, (float)v.y);
     }
-    __shared__ double red[2][4];
-    __shared__ float redm[4], redab[2][4];
+    __shared__ double red[2][16];
+    __shared__ float redm[16], redab[2][16];
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o));
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][wave] = s1; red[1][wave] = s2; redm[wave] = m2; }
     __syncthreads();
-    s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    s1 = 0.0; s2 = 0.0; m2 = 0.0f;
+    for (int w = 0; w < nwaves; ++w) {               // fixed order: the same sums on every run
+        s1 += red[0][w];
+        s2 += red[1][w];
+        m2 = fmaxf(m2, redm[w]);
+    }
     // every |x| of the group is at most the square root of the largest row's sum of squares
-    const float xmax = sqrtf(fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])));
+    const float xmax = sqrtf(m2);
     if (gamma == nullptr) {                          // bounds only (tensor consumed without a GroupNorm)
         if (threadIdx.x == 0 && bound != nullptr) {
             bound[(size_t)blockIdx.x * 2] = xmax;
@@ -273,8 +281,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(
         if ((threadIdx.x & 63) == 0) { redab[0][wave] = amax; redab[1][wave] = bmax; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            amax = fmaxf(fmaxf(redab[0][0], redab[0][1]), fmaxf(redab[0][2], redab[0][3]));
-            bmax = fmaxf(fmaxf(redab[1][0], redab[1][1]), fmaxf(redab[1][2], redab[1][3]));
+            amax = 0.0f; bmax = 0.0f;
+            for (int w = 0; w < nwaves; ++w) {
+                amax = fmaxf(amax, redab[0][w]);
+                bmax = fmaxf(bmax, redab[1][w]);
+            }
             bound[(size_t)blockIdx.x * 2] = fmaf(amax, xmax, bmax);
             bound[(size_t)blockIdx.x * 2 + 1] = xmax;
         }
@@ -316,7 +327,9 @@ hipError_t ddpm3d_launch_gn_finalize(const double* st0, int C0, int rows0, const
                                      const float* gamma, const float* beta, const float* film,
                                      int film_stride, int film_off, float* A, float* B, float* bound,
                                      hipStream_t st) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(256), 0, st, st0, C0, rows0, st1, C1,
+    const long long items = (long long)(rows0 > rows1 ? rows0 : rows1) * ((C0 + C1) / groups);   // double2 per group
+    const int threads = items >= 2048 ? 1024 : 256;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(threads), 0, st, st0, C0, rows0, st1, C1,
                        rows1, groups, count, eps, gamma, beta, film, film_stride, film_off, A, B, bound);
     return hipGetLastError();
 }

@@ -156,7 +156,11 @@ enum {
 /* ddpm3d_conv_desc.kernel_hint */
 enum {
     DDPM3D_HINT_WSTAT_OFF = 0x100,/* workgroup -> XCD order: tiles fastest (activation-stationary)   */
-    DDPM3D_HINT_WSTAT_ON = 0x200  /*   cout blocks / K splits fastest (weight-stationary)            */
+    DDPM3D_HINT_WSTAT_ON = 0x200, /*   cout blocks / K splits fastest (weight-stationary)            */
+    /* bits 12..14: issue order of a tap in the f16x3 Winograd-D kernel (conv3d_wz.h, IL + 1; 0 = the
+     * library picks by shape) */
+    DDPM3D_HINT_WZ_ORDER_SHIFT = 12,
+    DDPM3D_HINT_WZ_ORDER_MASK = 0x7000
 };
 
 int ddpm3d_abi_version(void);

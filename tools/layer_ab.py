@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=6)
     ap.add_argument("--only64", action="store_true", help="only the full-resolution layers")
+    ap.add_argument("--what", default="order", choices=["order", "issue"],
+                    help="order: workgroup -> XCD orders; issue: issue orders of a tap (f16x3 Winograd-D kernel)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model, _, _ = bench.build_model(bench.PUBLISHED, "250", dev)
@@ -48,7 +50,10 @@ def main():
         model(x, t, low_res=lr)                       # builds the plan, fills every buffer
     torch.cuda.synchronize()
     plan = model.engine().plan(B, S, S, S)
-    variants = [("default", 0), ("wstat_off", H.HINT_WSTAT_OFF), ("wstat_on", H.HINT_WSTAT_ON)]
+    ap_what = a.what
+    variants = {"order": [("default", 0), ("wstat_off", H.HINT_WSTAT_OFF), ("wstat_on", H.HINT_WSTAT_ON)],
+                # issue orders of a tap in the f16x3 Winograd-D kernel (conv3d_wz.h: IL)
+                "issue": [("default", 0)] + [("il%d" % il, (il + 1) << H.HINT_WZ_ORDER_SHIFT) for il in range(5)]}[ap_what]
     seen = {}
     print("# published architecture, %dx1x%d^3, %s; ms per launch (median of %d rounds x %d launches)"
           % (B, S, a.precision, a.rounds, a.iters))
