@@ -234,6 +234,14 @@ int ddpm3d_linear(const float* in, int rows, int K, const float* w, const float*
                     "linear");
 }
 
+int ddpm3d_add_embedding(float* emb, const float* table, const int64_t* idx, int rows, int dim, int num_classes,
+                         void* stream) {
+    if (!emb || !table || !idx || rows <= 0 || dim <= 0 || num_classes <= 0)
+        return fail(DDPM3D_EINVAL, "add_embedding: bad arguments");
+    (void)num_classes;   // the indices live on the device; the caller validates their range
+    return launched(ddpm3d_launch_add_embedding(emb, table, idx, rows, dim, (hipStream_t)stream), "add_embedding");
+}
+
 int ddpm3d_ncdhw_to_ndhwc(const float* in, int N, int C, int voxels, float* out, void* stream) {
     if (!in || !out || N <= 0 || C <= 0 || voxels <= 0) return fail(DDPM3D_EINVAL, "ncdhw_to_ndhwc: bad arguments");
     return launched(ddpm3d_launch_transpose(in, N, C, voxels, out, (hipStream_t)stream), "ncdhw_to_ndhwc");

@@ -488,8 +488,8 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     // (72 MFMAs) is shorter than the other half's staging phase, so the anti-phase halves wait for each
     // other.  Not kept (the form is commit 8797410's conv3d_wzp.h with the weight-ring depth made a template
     // parameter).
-    // f16x3: the issue order of a tap (interleaved / clumped prefetches) by shape, as measured
-    // (profiles/r02_layer_ab_wz_interleave.txt): interleaved except for the 384-cout layers.
+    // f16x3: the issue order of a tap (conv3d_wz.h, IL): one order for every shape since r03
+    // (profiles/r03_layer_ab_wz_issue_order.txt; r02 had picked between 0 and 1 by shape).
     if (c.PREC == DDPM3D_PREC_F16_WZ)
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     else if (c.PREC == DDPM3D_PREC_BF16_WZ)
@@ -497,13 +497,15 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     else {
         // kernel_hint bits 12..14: force an issue order (A/B measurements; identical arithmetic), 0 = by shape
         int order = (k.hint & DDPM3D_HINT_WZ_ORDER_MASK) >> DDPM3D_HINT_WZ_ORDER_SHIFT;
-        if (order == 0) order = k.CoutPad % 384 != 0 ? 2 : 1;   // (value = IL + 1)
+        if (order == 0) order = 5;   // (value = IL + 1): weight loads first, reads behind, wave priority 1
         switch (order - 1) {
             case 0: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 0>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
             case 1: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 1>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
             case 2: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 2>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
             case 3: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 3>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
             case 4: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
+            case 5: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 5>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
+            case 6: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 6>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
             default: return hipErrorInvalidValue;
         }
     }

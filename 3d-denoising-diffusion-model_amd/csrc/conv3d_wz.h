@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         // box, bf16 DDIM-50: R = 3 / 4 / 6 / 8 / 9 -> 2.19 / 2.34 / 2.42 / 2.48 / 2.39 volumes/s; the
         // A operands one tap ahead as below: two ahead -1.5 %, three -16 %).  The stream's byte
         // offset is one running scalar
-        if constexpr (IL >= 3) __builtin_amdgcn_s_setprio(1);
+        if constexpr (IL == 3 || IL == 4 || IL == 6) __builtin_amdgcn_s_setprio(1);
         unsigned woff = (unsigned)chunk * wchunk_stride;
         auto bump = [&]() {
             woff += wtap_stride;
@@ -189,6 +189,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
+            } else if constexpr (IL == 5 || IL == 6) {
+#pragma unroll
+                for (int i = 0; i < (X3 ? 2 : 1); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < (X3 ? 2 : 1); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
             } else if constexpr (IL == 2 || IL == 4) {
 #pragma unroll
                 for (int i = 0; i < (X3 ? 2 : 1); ++i) {
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
                 }
             }
         }
-        if constexpr (IL >= 3) __builtin_amdgcn_s_setprio(0);
+        if constexpr (IL == 3 || IL == 4 || IL == 6) __builtin_amdgcn_s_setprio(0);
         WZ_STAMP(6 + (chunk - chunk_begin) * 5);
     }
     WZ_STAMP(42);

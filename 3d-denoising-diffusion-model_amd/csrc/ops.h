@@ -27,6 +27,8 @@ hipError_t ddpm3d_launch_sample_step(bool ddim, const float* mo, const float* x,
 hipError_t ddpm3d_launch_attention(const float* qkv, int N, int T, int heads, int ch, int precision,
                                    const float* bound, int bound_count, int bound_stride, float* out,
                                    hipStream_t st);
+hipError_t ddpm3d_launch_add_embedding(float* emb, const float* table, const int64_t* idx, int rows, int dim,
+                                       hipStream_t st);
 // probe.hip
 double ddpm3d_probe_flops_per_iter(int kind);
 hipError_t ddpm3d_launch_mfma_probe(int kind, int iters, int blocks, float* out, unsigned long long* clk,

@@ -415,6 +415,23 @@ hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, c
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------ label embedding
+// emb[r][:] += table[idx[r]][:]  (unet.py:703-705: emb = emb + self.label_emb(y))
+__global__ void add_embedding_kernel(float* __restrict__ emb, const float* __restrict__ table,
+                                     const int64_t* __restrict__ idx, int rows, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * dim) return;
+    const int r = i / dim, j = i - r * dim;
+    emb[i] += table[(size_t)idx[r] * dim + j];
+}
+
+hipError_t ddpm3d_launch_add_embedding(float* emb, const float* table, const int64_t* idx, int rows, int dim,
+                                       hipStream_t st) {
+    const int total = rows * dim;
+    hipLaunchKernelGGL(add_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, st, emb, table, idx, rows, dim);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ linear
 // One wave per output feature o, LIN_ROWS rows of the batch at a time: the
 // weight row is read once (coalesced 256-B segments) and reused across rows.

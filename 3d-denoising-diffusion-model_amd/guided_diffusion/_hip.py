@@ -76,6 +76,7 @@ EXPORTS = {
     "ddpm3d_p_sample_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "ddpm3d_ddim_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float,
                                    _fp, _fp, _fp]),
+    "ddpm3d_add_embedding": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
     "ddpm3d_mfma_probe_flops_per_iter": (C.c_double, [C.c_int]),
     "ddpm3d_mfma_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
 }

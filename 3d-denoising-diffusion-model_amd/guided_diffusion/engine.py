@@ -86,10 +86,29 @@ class UNetEngine:
         self.winograd = winograd
         # planar: the SuperRes first conv reads x and low_res as two single-channel volumes; otherwise
         # the input is an ordinary (N, in_channels, ...) tensor, padded to 16 channels at the edge
+        if planar and in_channels != 2:
+            raise ValueError("the planar first conv reads ONE image and ONE low_res channel (got in_channels=%d)"
+                             % in_channels)
         self.planar = planar
         self.in_channels = in_channels
         self.cin_pad = (in_channels + 15) // 16 * 16
         first = topo.input[0][0].prefix
+        # QKVAttention ("new order", unet.py:361-389) splits the qkv conv's 3C outputs as q | k | v, each
+        # heads x ch wide; the attention kernel reads the legacy layout (per head: q | k | v).  Same
+        # arithmetic either way, so the conv's output channels are permuted once, here, at pack time.
+        qkv_perm = {}
+        if getattr(topo, "new_attention_order", False):
+            for e in topo.all_layers():
+                if e.kind == "attn":
+                    Cn, ch = e.cin, e.cin // e.heads
+                    leg = torch.arange(3 * Cn)
+                    h, part, i = leg // (3 * ch), (leg // ch) % 3, leg % ch
+                    qkv_perm[e.prefix + ".qkv"] = (part * Cn + h * ch + i).to(device)
+        params = dict(params)
+        for base, perm in qkv_perm.items():
+            params[base + ".weight"] = params[base + ".weight"][perm].contiguous()
+            params[base + ".bias"] = params[base + ".bias"][perm].contiguous()
+        self.p = params
         for name, t in params.items():
             if name.endswith(".weight") and t.dim() >= 3:
                 base = name[:-len(".weight")]
@@ -141,8 +160,8 @@ class UNetEngine:
         torch.cuda.current_stream().synchronize()
 
     # ------------------------------------------------------------ timestep path
-    def film_rows(self, t_float):
-        """[R] timesteps (float, original-process index) -> [R, film_total]."""
+    def film_rows(self, t_float, y=None):
+        """[R] timesteps (float, original-process index) [+ [R] int64 class labels] -> [R, film_total]."""
         lib, st, p = self.lib, H.stream(), self.p
         R = t_float.numel()
         dev = self.device
@@ -155,6 +174,10 @@ class UNetEngine:
                                   H.ptr(p["time_embed.0.bias"]), self.ted, 0, H.ptr(e1), self.ted, st))
         H.check(lib.ddpm3d_linear(H.ptr(e1), R, self.ted, H.ptr(p["time_embed.2.weight"]),
                                   H.ptr(p["time_embed.2.bias"]), self.ted, 1, H.ptr(e2), self.ted, st))
+        if y is not None:
+            # emb = time_embed(.) + label_emb(y), unet.py:703-705
+            table = p["label_emb.weight"]
+            H.check(lib.ddpm3d_add_embedding(H.ptr(e2), H.ptr(table), H.ptr(y), R, self.ted, table.shape[0], st))
         H.check(lib.ddpm3d_linear(H.ptr(e2), R, self.ted, H.ptr(self.emb_w), H.ptr(self.emb_b),
                                   self.film_total, 1, H.ptr(rows), self.film_total, st))
         return rows

@@ -38,7 +38,10 @@ class Topology:
 
     def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  channel_mult, num_heads, num_head_channels, num_heads_upsample, resblock_updown,
-                 mid_attention):
+                 mid_attention, new_attention_order=False):
+        # QKVAttention instead of QKVAttentionLegacy in every AttentionBlock (unet.py:287-292)
+        self.new_attention_order = bool(new_attention_order)
+
         def nheads(ch, n):
             return n if num_head_channels == -1 else ch // num_head_channels
 
@@ -182,14 +185,10 @@ class UNetModel_noatt(nn.Module):
         super().__init__()
         if dims not in (2, 3):
             raise NotImplementedError("the HIP engine implements the 2-D and 3-D models (dims 2 or 3)")
-        if num_classes is not None:
-            raise NotImplementedError("class conditioning is unused by the 3-D PET model")
         # dropout: nn.Dropout is the identity in eval mode (unet.py:209), and this package only
         # samples -- any p is accepted and ignored
         if not conv_resample and not resblock_updown:
             raise NotImplementedError("conv_resample=False")
-        if use_new_attention_order:
-            raise NotImplementedError("use_new_attention_order is unreachable from the SR factory")
         if num_heads_upsample == -1:
             num_heads_upsample = num_heads
         self.image_size = image_size
@@ -214,10 +213,13 @@ class UNetModel_noatt(nn.Module):
 
         self.topology = Topology(in_channels, model_channels, out_channels, num_res_blocks,
                                  tuple(attention_resolutions), tuple(channel_mult), num_heads,
-                                 num_head_channels, num_heads_upsample, resblock_updown, self.MID_ATTENTION)
+                                 num_head_channels, num_heads_upsample, resblock_updown, self.MID_ATTENTION,
+                                 use_new_attention_order)
         ted = 4 * model_channels
         t = self.topology
         self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
+        if num_classes is not None:
+            self.label_emb = nn.Embedding(num_classes, ted)     # unet.py:476-478
         self.input_blocks = nn.ModuleList(
             [_Block(*[_container(l, ted, use_scale_shift_norm, dims) for l in blk]) for blk in t.input])
         self.middle_block = _Block(*[_container(l, ted, use_scale_shift_norm, dims) for l in t.middle])
@@ -269,17 +271,24 @@ class UNetModel_noatt(nn.Module):
             with torch.cuda.device(p0.device):
                 self._engine = UNetEngine(self.topology, params, self.model_channels,
                                           self.use_scale_shift_norm, p0.device, self.conv_precision,
-                                          in_channels=self.in_channels, planar=self.PLANAR_INPUT,
+                                          in_channels=self.in_channels, planar=self._planar(),
                                           winograd=self.dims == 3)
             self._engine_key = key
         return self._engine
 
     PLANAR_INPUT = False   # SuperRes models: the first conv reads x and low_res as two planes
 
+    def _planar(self):
+        """The two-pointer first conv serves the case every caller in the reference has: one image
+        channel + one low_res channel.  A SuperRes model with more channels (the reference's RGB
+        super-resolution networks) concatenates at the API edge like unet.py:1693 does."""
+        return self.PLANAR_INPUT and self.in_channels == 2
+
     def forward(self, x, timesteps, y=None, low_res=None):
         """unet.py:687-716 / :1015-1044.  x: (N, in_channels, [D,] H, W).  The SuperRes subclasses
         pass low_res, which supplies the second input channel (unet.py:1687-1694)."""
-        assert y is None, "must specify y if and only if the model is class-conditional"
+        assert (y is not None) == (self.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
         if self.PLANAR_INPUT and low_res is None:
             raise RuntimeError("the super-resolution model is conditional: pass low_res=... (unet.py:1687)")
         if not self.PLANAR_INPUT and low_res is not None:
@@ -290,12 +299,27 @@ class UNetModel_noatt(nn.Module):
         if flat != (self.dims == 2):
             raise RuntimeError("a dims=%d model takes %d-D tensors" % (self.dims, self.dims + 2))
         with torch.cuda.device(x.device):
-            rows = eng.film_rows(timesteps.to(device=x.device, dtype=torch.float32).contiguous())
+            yy = None
+            if y is not None:
+                assert tuple(y.shape) == (x.shape[0],)
+                yy = y.to(device=x.device, dtype=torch.int64).contiguous()
+                if int(yy.min()) < 0 or int(yy.max()) >= self.num_classes:     # nn.Embedding's own check
+                    raise IndexError("class label out of range [0, %d)" % self.num_classes)
+            rows = eng.film_rows(timesteps.to(device=x.device, dtype=torch.float32).contiguous(), yy)
             xv = x.unsqueeze(2) if flat else x
             lr = None
             if low_res is not None:
                 lr = low_res.to(x.device).contiguous()
                 lr = lr.unsqueeze(2) if flat else lr
+                if not self._planar():
+                    # more than one image channel: th.cat([x, low_res], dim=1) (unet.py:1693) at the edge
+                    if lr.shape[0] != xv.shape[0] or lr.shape[2:] != xv.shape[2:]:
+                        raise RuntimeError("low_res %s does not match x %s" % (tuple(lr.shape), tuple(xv.shape)))
+                    xv = torch.cat([xv, lr.to(xv.dtype)], dim=1).contiguous()
+                    lr = None
+                elif xv.shape[1] != 1 or lr.shape[1] != 1:
+                    raise RuntimeError("x and low_res must have one channel each (got %d and %d)"
+                                       % (xv.shape[1], lr.shape[1]))
             out = eng.forward(xv, lr, rows, eng.film_total).clone()
             return out.squeeze(2) if flat else out
 
@@ -315,7 +339,7 @@ class SuperResModel_noatt(UNetModel_noatt):
         super().__init__(image_size, int(in_channels * 2), *args, **kwargs)
 
     def forward(self, x, timesteps, low_res=None, **kwargs):
-        return super().forward(x, timesteps, low_res=low_res, **kwargs)
+        return super().forward(x, timesteps, low_res=low_res, **kwargs)   # y=... passes through (unet.py:1694)
 
 
 class SuperResModel(UNetModel):

@@ -257,9 +257,19 @@ int ddpm3d_timestep_embedding(const float* t, int rows, int dim, const float* fr
 int ddpm3d_linear(const float* in, int rows, int K, const float* w, const float* bias,
                   int O, int silu_in, float* out, int out_stride, void* stream);
 
+/* Class conditioning (unet.py:476-478, :703-705): emb[r][:] += table[idx[r]][:] with table =
+ * label_emb.weight [num_classes][dim] and idx = the batch's labels (int64, device; each in
+ * [0, num_classes) -- validated by the caller, as nn.Embedding does on the host side). */
+int ddpm3d_add_embedding(float* emb, const float* table, const int64_t* idx, int rows, int dim, int num_classes,
+                         void* stream);
+
 /*
  * Self-attention core of AttentionBlock (unet.py:296-305) with the legacy head layout
- * (QKVAttentionLegacy, unet.py:337-354): qkv = [N][T][heads*3*ch] (per head: q | k | v),
+ * (QKVAttentionLegacy, unet.py:337-354): qkv = [N][T][heads*3*ch] (per head: q | k | v).
+ * The other order (QKVAttention, unet.py:361-389: q | k | v each heads*ch wide, same scale, same
+ * softmax, same output order) differs only in which rows of the qkv 1x1 conv feed which slot: the
+ * host permutes that conv's output channels when it packs the weights and calls this same kernel.
+ * qkv layout here:
  * out = [N][T][heads*ch];  out = softmax_fp32((q s)^T (k s)) v^T with s = ch^-1/4.
  * Streaming softmax: the T x T weight matrix the reference materialises (:349-353) never
  * exists.  The GroupNorm and the qkv / proj_out 1x1 convs around it are ddpm3d_conv3d calls.

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 def sr_config(large_size=256, num_channels=128, num_res_blocks=2, learn_sigma=False,
               attention_resolutions="16,8", num_heads=4, num_head_channels=-1,
               num_heads_upsample=-1, use_scale_shift_norm=True, resblock_updown=False,
-              mid_attention=False, **_ignored):
+              mid_attention=False, class_cond=False, **_ignored):
     if large_size in (512, 256):
         mult = (1, 1, 2, 2, 4, 4)
     elif large_size == 64:
@@ -44,12 +44,14 @@ def sr_config(large_size=256, num_channels=128, num_res_blocks=2, learn_sigma=Fa
         use_scale_shift_norm=use_scale_shift_norm,
         resblock_updown=resblock_updown,
         mid_attention=mid_attention,  # False = UNetModel_noatt, True = UNetModel
+        num_classes=1000 if class_cond else None,   # script_util.py:8, :442
     )
 
 
 def model2d_config(image_size=64, num_channels=128, num_res_blocks=2, channel_mult="", learn_sigma=False,
                    attention_resolutions="16", num_heads=1, num_head_channels=-1, num_heads_upsample=-1,
-                   use_scale_shift_norm=False, resblock_updown=False, **_ignored):
+                   use_scale_shift_norm=False, resblock_updown=False, class_cond=False,
+                   use_new_attention_order=False, **_ignored):
     """script_util.py:130-184 (create_model): the 2-D RGB UNetModel."""
     if channel_mult == "":
         mult = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4),
@@ -62,7 +64,8 @@ def model2d_config(image_size=64, num_channels=128, num_res_blocks=2, channel_mu
         attention_ds=tuple(image_size // int(r) for r in attention_resolutions.split(",")),
         channel_mult=mult, num_heads=num_heads, num_head_channels=num_head_channels,
         num_heads_upsample=num_heads if num_heads_upsample == -1 else num_heads_upsample,
-        use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown, mid_attention=True)
+        use_scale_shift_norm=use_scale_shift_norm, resblock_updown=resblock_updown, mid_attention=True,
+        num_classes=1000 if class_cond else None, new_attention_order=use_new_attention_order)
 
 
 # --------------------------------------------------------------------------
@@ -142,6 +145,8 @@ def param_shapes(cfg):
     ted = 4 * mc
     res = [("time_embed.0.weight", (ted, mc)), ("time_embed.0.bias", (ted,)),
            ("time_embed.2.weight", (ted, ted)), ("time_embed.2.bias", (ted,))]
+    if cfg.get("num_classes") is not None:
+        res.append(("label_emb.weight", (cfg["num_classes"], ted)))     # unet.py:476-478
     topo = topology(cfg)
     k3 = (3,) * cfg.get("dims", 3)
     k1 = (1,) * cfg.get("dims", 3)
@@ -250,15 +255,18 @@ def resblock(sd, p, x, emb, updown, film):
     return x + h
 
 
-def attention(sd, p, x, n_heads):
-    # unet.py:296-305 and QKVAttentionLegacy :337-354
+def attention(sd, p, x, n_heads, new_order=False):
+    # unet.py:296-305; QKVAttentionLegacy :337-354, or (new_order) QKVAttention :361-389
     b, c = x.shape[:2]
     spatial = x.shape[2:]
     xf = x.reshape(b, c, -1)
     qkv = F.conv1d(gn32(sd, p + ".norm", xf), sd[p + ".qkv.weight"], sd[p + ".qkv.bias"])
     length = qkv.shape[-1]
     ch = c // n_heads
-    q, k, v = qkv.reshape(b * n_heads, ch * 3, length).split(ch, dim=1)
+    if new_order:
+        q, k, v = (t.reshape(b * n_heads, ch, length) for t in qkv.chunk(3, dim=1))
+    else:
+        q, k, v = qkv.reshape(b * n_heads, ch * 3, length).split(ch, dim=1)
     s = 1 / math.sqrt(math.sqrt(ch))
     w = torch.einsum("bct,bcs->bts", q * s, k * s)
     w = torch.softmax(w.float(), dim=-1).type(w.dtype)
@@ -274,7 +282,7 @@ def run_layer(sd, cfg, entry, h, emb):
     if kind == "res":
         return resblock(sd, p, h, emb, entry[4], cfg["use_scale_shift_norm"])
     if kind == "attn":
-        return attention(sd, p, h, entry[3])
+        return attention(sd, p, h, entry[3], cfg.get("new_attention_order", False))
     if kind == "downconv":
         return conv(h, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=(1, 2, 2) if h.dim() == 5 else 2,
                     padding=1)
@@ -283,7 +291,7 @@ def run_layer(sd, cfg, entry, h, emb):
     raise ValueError(kind)
 
 
-def unet_forward(sd, cfg, x, timesteps, low_res=None, taps=None):
+def unet_forward(sd, cfg, x, timesteps, low_res=None, taps=None, y=None):
     """x: (N,1,D,H,W); low_res same shape (SuperRes concat, unet.py:1690-1693);
     returns (N,out_channels,D,H,W).  ``taps``: optional dict that receives
     named intermediate activations for layer-level parity tests."""
@@ -294,6 +302,9 @@ def unet_forward(sd, cfg, x, timesteps, low_res=None, taps=None):
     emb = timestep_embedding(timesteps, mc)
     emb = F.linear(emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     emb = F.linear(F.silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    assert (y is not None) == (cfg.get("num_classes") is not None)      # unet.py:696-698
+    if y is not None:
+        emb = emb + sd["label_emb.weight"][y]                            # unet.py:703-705
     h = x.float()
     hs = []
     for k, blk in enumerate(topo["input"]):

@@ -387,6 +387,50 @@ def gen_script_tiling():
     save("script_tiling.npz", **out)
 
 
+def gen_api_extras():
+    """The two factory flags the SR launcher never sets but create_model_and_diffusion /
+    sr_create_model_and_diffusion expose: class conditioning (label_emb,
+    unet.py:476-478, :703-705) and the other attention order (QKVAttention, unet.py:361-389).
+    Outputs of the reference on seeded weights: a class-conditional tiny 3-D SR network (forward and a
+    3-step p_sample_loop with y in model_kwargs), a 2-D network with use_new_attention_order (forward and
+    a 6-step loop), and a class-conditional 2-D network in the new order.  Keys + shapes of each."""
+    out, keys = {}, {}
+    # 3-D SR, class_cond
+    fl = flags(**dict(TINY, class_cond=True, timestep_respacing="3"))
+    model, diff = ref_su.sr_create_model_and_diffusion(**fl)
+    keys["sr_class_cond"] = load_synth(model, seed=4)
+    shape = (2, 1, 4, 16, 16)
+    x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0])
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234))
+    y = torch.tensor([3, 977])
+    with torch.no_grad():
+        out["sr_class_cond/forward"] = model(x, torch.tensor([37, 999]), low_res=lr, y=y).numpy()
+    draws = synth.synth_noise(shape, diff.num_timesteps + 1, seed=10)
+    with _InjectNoise(draws[1:]), torch.no_grad():
+        out["sr_class_cond/ddpm3"] = diff.p_sample_loop(model, shape, noise=torch.from_numpy(draws[0]),
+                                                        model_kwargs={"low_res": lr, "y": y}).numpy()
+    out["sr_class_cond/y"] = y.numpy()
+    # 2-D, new attention order (+ class_cond)
+    for tag, over in (("new_order", dict(use_new_attention_order=True)),
+                      ("new_order_class_cond", dict(use_new_attention_order=True, class_cond=True,
+                                                    num_head_channels=-1, num_heads=2))):
+        fl2 = model2d_flags(**over)
+        model, diff = ref_su.create_model_and_diffusion(**fl2)
+        keys[tag] = load_synth(model, seed=2)
+        shape = (2, 3, 32, 48)
+        x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0])
+        kw = {"y": torch.tensor([5, 0])} if over.get("class_cond") else {}
+        with torch.no_grad():
+            out[tag + "/forward"] = model(x, torch.tensor([617, 3]), **kw).numpy()
+        draws = synth.synth_noise(shape, diff.num_timesteps + 1, seed=10)
+        with _InjectNoise(draws[1:]), torch.no_grad():
+            out[tag + "/ddpm"] = diff.p_sample_loop(model, shape, noise=torch.from_numpy(draws[0]),
+                                                    model_kwargs=kw).numpy()
+    with open(os.path.join(HERE, "api_extras_keys.json"), "w") as f:
+        json.dump(keys, f)
+    save("api_extras.npz", **out)
+
+
 def model2d_flags(**over):
     """create_model_and_diffusion's flag set (script_util.py:41-66) at a CPU-sized 2-D RGB network:
     attention at ds 4 and in the middle block, conv down/upsampling (resblock_updown False)."""
@@ -428,7 +472,7 @@ def gen_model2d():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "temb", "keys", "resblocks", "unet", "sampler", "helpers", "tiling", "model2d"]
+    which = sys.argv[1:] or ["schedules", "temb", "keys", "resblocks", "unet", "sampler", "helpers", "tiling", "model2d", "api_extras"]
     if "schedules" in which:
         gen_schedules()
     if "temb" in which:
@@ -447,5 +491,7 @@ if __name__ == "__main__":
         gen_script_helpers()
     if "tiling" in which:
         gen_script_tiling()
+    if "api_extras" in which:
+        gen_api_extras()
     if "sampler250" in which:       # ~10 CPU-minutes; not part of the default list
         gen_sampler_published250()

@@ -345,3 +345,85 @@ def test_model2d_forward_and_loops_vs_reference_golden(golden, tag, precision):
     assert ea < 1e-3 and eb < 1e-3              # the north_star bar, as for the 3-D loops above
     with pytest.raises(RuntimeError):
         model(x.unsqueeze(2), torch.tensor([617, 3]).cuda())      # a dims=2 model takes 4-D tensors
+
+
+# ---------------------------------------------------------------- class conditioning, new attention order
+def test_class_conditional_sr_model_vs_reference_golden(golden):
+    """class_cond=True through sr_create_model_and_diffusion (script_util.py:442: label_emb of 1000
+    classes, unet.py:476-478, :703-705): forward with y and a 3-step p_sample_loop with y in
+    model_kwargs, against the reference's outputs; a missing / out-of-range y fails like the reference."""
+    fl = su.sr_model_and_diffusion_defaults()
+    fl.update(TINY, class_cond=True, timestep_respacing="3")
+    model, diff = su.sr_create_model_and_diffusion(**fl)
+    model.load_state_dict({k: torch.from_numpy(synth.synth_param(k, tuple(v.shape), 4))
+                           for k, v in model.state_dict().items()})
+    model.to("cuda").eval()
+    g = golden("api_extras.npz")
+    shape = (2, 1, 4, 16, 16)
+    x, lr = inputs(shape)
+    y = torch.from_numpy(g["sr_class_cond/y"]).cuda()
+    with torch.no_grad():
+        out = model(x.cuda(), torch.tensor([37, 999]).cuda(), low_res=lr.cuda(), y=y)
+    assert rel_err_per_channel(out.cpu().numpy(), g["sr_class_cond/forward"]) < 1e-4
+    draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, 4, seed=10)]
+    a = diff.p_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr.cuda(), "y": y}, step_noise=draws[1:])
+    assert rel_err(a.cpu().numpy(), g["sr_class_cond/ddpm3"]) < 1e-3
+    with pytest.raises(AssertionError):
+        model(x.cuda(), torch.tensor([37, 999]).cuda(), low_res=lr.cuda())
+    with pytest.raises(IndexError):
+        model(x.cuda(), torch.tensor([37, 999]).cuda(), low_res=lr.cuda(), y=torch.tensor([0, 1000]).cuda())
+
+
+@pytest.mark.parametrize("tag,over", [
+    ("new_order", dict(use_new_attention_order=True)),
+    ("new_order_class_cond", dict(use_new_attention_order=True, class_cond=True, num_head_channels=-1, num_heads=2)),
+])
+def test_new_attention_order_vs_reference_golden(golden, tag, over):
+    """use_new_attention_order=True (QKVAttention, unet.py:361-389) through create_model_and_diffusion: the
+    qkv conv's output channels are permuted at pack time and the same attention kernel runs; forward
+    and a 6-step loop against the reference (with class conditioning in the second variant)."""
+    fl = su.model_and_diffusion_defaults()
+    fl.update(image_size=64, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", num_head_channels=32,
+              attention_resolutions="16", learn_sigma=True, use_scale_shift_norm=True, timestep_respacing="6")
+    fl.update(over)
+    model, diff = su.create_model_and_diffusion(**fl)
+    model.load_state_dict({k: torch.from_numpy(synth.synth_param(k, tuple(v.shape), 2))
+                           for k, v in model.state_dict().items()})
+    model.to("cuda").eval()
+    g = golden("api_extras.npz")
+    shape = (2, 3, 32, 48)
+    x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0]).cuda()
+    kw = {"y": torch.tensor([5, 0]).cuda()} if over.get("class_cond") else {}
+    with torch.no_grad():
+        out = model(x, torch.tensor([617, 3]).cuda(), **kw)
+    assert rel_err_per_channel(out.cpu().numpy(), g[tag + "/forward"]) < 2e-5
+    draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, 7, seed=10)]
+    a = diff.p_sample_loop(model, shape, draws[0], model_kwargs=kw, step_noise=draws[1:])
+    assert rel_err(a.cpu().numpy(), g[tag + "/ddpm"]) < 1e-3
+
+
+def test_superres_model_with_several_image_channels():
+    """A SuperRes model built directly with in_channels != 1 (the reference's RGB super-resolution
+    networks): the two-pointer planar first conv is for one image + one low_res channel
+    only, so such a model concatenates at the edge (unet.py:1693) -- and must equal the oracle."""
+    from guided_diffusion.unet import SuperResModel_noatt
+    from oracle import unet_ref
+    model = SuperResModel_noatt(96, 3, 32, 6, 1, (), channel_mult=(1, 2), dims=3, num_head_channels=32,
+                                use_scale_shift_norm=True, resblock_updown=True)
+    model.load_state_dict({k: torch.from_numpy(synth.synth_param(k, tuple(v.shape), 6))
+                           for k, v in model.state_dict().items()})
+    model.to("cuda").eval()
+    shape = (1, 3, 4, 16, 16)
+    x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0])
+    lr = torch.from_numpy(synth.synth_noise(shape, 1, seed=5)[0])
+    with torch.no_grad():
+        out = model(x.cuda(), torch.tensor([11]).cuda(), low_res=lr.cuda())
+    cfg = dict(in_channels=6, model_channels=32, out_channels=6, num_res_blocks=1, attention_ds=(), channel_mult=(1, 2),
+               num_heads=1, num_head_channels=32, num_heads_upsample=1, use_scale_shift_norm=True,
+               resblock_updown=True, mid_attention=False)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(sd, cfg, x, torch.tensor([11]), lr)
+    assert rel_err_per_channel(out.cpu().numpy(), ref.numpy()) < 1e-4
+    with pytest.raises(RuntimeError):
+        model(x.cuda(), torch.tensor([11]).cuda(), low_res=lr[:, :, :2].cuda())

@@ -183,8 +183,6 @@ def test_unsupported_features_fail_loudly():
     from guided_diffusion.unet import UNetModel_noatt
     with pytest.raises(NotImplementedError):
         UNetModel_noatt(32, 2, 32, 2, 1, (), dims=1)
-    with pytest.raises(NotImplementedError):
-        UNetModel_noatt(32, 2, 32, 2, 1, (), dims=3, num_classes=10)
     d = su.create_gaussian_diffusion()
     with pytest.raises(NotImplementedError):
         next(d.p_sample_loop_progressive(None, (1, 1, 2, 2, 2), cond_fn=lambda *a: 0))
@@ -208,3 +206,28 @@ def test_model2d_state_dict_layout_matches_reference():
         assert diff.num_timesteps == 6 and model.dims == 2
         with pytest.raises(RuntimeError):          # no CPU path
             model(torch.zeros(1, 3, 32, 32), torch.zeros(1))
+
+
+def test_class_cond_and_new_attention_order_layouts_match_reference():
+    """class_cond adds label_emb.weight right behind time_embed (unet.py:476-478); use_new_attention_order
+    changes no key: state_dict keys and shapes of three such models equal the reference's
+    (tests/golden/api_extras_keys.json)."""
+    import json
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "api_extras_keys.json")) as f:
+        ref = json.load(f)
+    fl = su.sr_model_and_diffusion_defaults()
+    fl.update(large_size=96, small_size=96, num_channels=32, num_res_blocks=1, num_head_channels=64,
+              attention_resolutions="1000", learn_sigma=True, resblock_updown=True, use_scale_shift_norm=True,
+              class_cond=True)
+    model, _ = su.sr_create_model_and_diffusion(**fl)
+    assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == ref["sr_class_cond"]
+    f2 = su.model_and_diffusion_defaults()
+    f2.update(image_size=64, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", num_head_channels=32,
+              attention_resolutions="16", learn_sigma=True, use_scale_shift_norm=True, timestep_respacing="6")
+    for tag, over in (("new_order", dict(use_new_attention_order=True)),
+                      ("new_order_class_cond", dict(use_new_attention_order=True, class_cond=True,
+                                                    num_head_channels=-1, num_heads=2))):
+        model, _ = su.create_model_and_diffusion(**dict(f2, **over))
+        assert model.topology.new_attention_order
+        assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == ref[tag], tag

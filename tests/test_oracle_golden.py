@@ -225,3 +225,61 @@ def test_model2d_oracle_vs_reference(golden, tag):
                                          learn_sigma=fl["learn_sigma"])
     assert rel_err(a.numpy(), g[tag + "/ddpm"]) < 1e-5
     assert rel_err(b.numpy(), g[tag + "/ddim"]) < 1e-5
+
+
+# ------------------------------------------- class conditioning and the other attention order
+API_EXTRAS_2D = {
+    "new_order": dict(use_new_attention_order=True),
+    "new_order_class_cond": dict(use_new_attention_order=True, class_cond=True, num_head_channels=-1, num_heads=2),
+}
+
+
+def test_class_conditional_sr_oracle_vs_reference(golden):
+    """label_emb (unet.py:476-478, :703-705) on the 3-D SR network: layout, forward with y, and a 3-step
+    p_sample_loop with y in model_kwargs -- against the reference (tests/golden/api_extras.npz)."""
+    tiny = dict(large_size=96, num_channels=32, num_res_blocks=1, num_head_channels=64, attention_resolutions="1000",
+                learn_sigma=True, resblock_updown=True, use_scale_shift_norm=True, class_cond=True)
+    cfg = unet_ref.sr_config(**tiny)
+    with open(os.path.join(GOLDEN, "api_extras_keys.json")) as f:
+        ref_keys = json.load(f)["sr_class_cond"]
+    assert [[k, list(s)] for k, s in unet_ref.param_shapes(cfg)] == ref_keys
+    sd = _sd(cfg, seed=4)
+    g = golden("api_extras.npz")
+    shape = (2, 1, 4, 16, 16)
+    x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0])
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234))
+    y = torch.from_numpy(g["sr_class_cond/y"])
+    with torch.no_grad():
+        out = unet_ref.unet_forward(sd, cfg, x, torch.tensor([37, 999]), lr, y=y).numpy()
+    assert rel_err(out, g["sr_class_cond/forward"]) < 1e-6
+    tmap, tb = schedule_ref.spaced_schedule(1000, "linear", "3")
+    draws = [torch.from_numpy(a) for a in synth.synth_noise(shape, 4, seed=10)]
+    with torch.no_grad():
+        a = sampler_ref.p_sample_loop(lambda xx, t, c: unet_ref.unet_forward(sd, cfg, xx, t, c, y=y), tmap, tb,
+                                      draws[0], draws[1:], lr)
+    assert rel_err(a.numpy(), g["sr_class_cond/ddpm3"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", sorted(API_EXTRAS_2D))
+def test_new_attention_order_oracle_vs_reference(golden, tag):
+    """QKVAttention (unet.py:361-389) in the 2-D network, alone and with class conditioning."""
+    fl = dict(MODEL2D, **API_EXTRAS_2D[tag])
+    cfg = unet_ref.model2d_config(**fl)
+    assert cfg["new_attention_order"]
+    with open(os.path.join(GOLDEN, "api_extras_keys.json")) as f:
+        ref_keys = json.load(f)[tag]
+    assert [[k, list(s)] for k, s in unet_ref.param_shapes(cfg)] == ref_keys
+    sd = _sd(cfg, seed=2)
+    g = golden("api_extras.npz")
+    shape = (2, 3, 32, 48)
+    x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0])
+    y = torch.tensor([5, 0]) if fl.get("class_cond") else None
+    with torch.no_grad():
+        out = unet_ref.unet_forward(sd, cfg, x, torch.tensor([617, 3]), y=y).numpy()
+    assert rel_err(out, g[tag + "/forward"]) < 1e-6
+    tmap, tb = schedule_ref.spaced_schedule(1000, "linear", "6")
+    draws = [torch.from_numpy(a) for a in synth.synth_noise(shape, 7, seed=10)]
+    with torch.no_grad():
+        a = sampler_ref.p_sample_loop(lambda xx, t, _: unet_ref.unet_forward(sd, cfg, xx, t, y=y), tmap, tb,
+                                      draws[0], draws[1:], None)
+    assert rel_err(a.numpy(), g[tag + "/ddpm"]) < 1e-5
