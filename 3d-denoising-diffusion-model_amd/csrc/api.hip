@@ -105,6 +105,19 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
 
     ConvCfg c = ddpm3d_conv_cfg(d->N, d->D, d->H, d->W, d->Cin, d->Cout, d->ksize);
     c.PREC = d->precision;
+    if (d->kernel_hint & DDPM3D_HINT_SPLITK_MASK) {
+        // measurement only (tools/splitk_sweep.py): force the split factor; the caller sizes the workspace
+        // for it and passes no statistics (their row count follows the library's own choice)
+        const int s_forced = (d->kernel_hint & DDPM3D_HINT_SPLITK_MASK) >> DDPM3D_HINT_SPLITK_SHIFT;
+        const int nch = ddpm3d_cin_pad(d->Cin) / DDPM3D_CONV_CK;
+        if (d->stats || s_forced > nch || d->ksize != 3 || c.WN != 4)
+            return fail(DDPM3D_EINVAL, "conv3d: a forced split factor needs ksize 3, Cout > 64, no statistics, S <= Cin / 16");
+        c.S = s_forced;
+        c.workspace_bytes = s_forced > 1 ? (size_t)s_forced * d->N * d->D * d->H * d->W * d->Cout * sizeof(float) : 0;
+        const long long vox = (long long)d->D * d->H * d->W;
+        c.stats_rows = s_forced > 1 ? (int)((vox + c.reduce_vox - 1) / c.reduce_vox)
+                                    : c.tilesZ * c.tilesY * c.tilesX * (4 / c.WN);   // (the reduce kernel's grid)
+    }
     if (prec_wz(d->precision) &&
         !(wz_layer_ok(d->Cout, d->Cin, d->ksize) && c.TXL == 3 && c.WN == 4 && c.MT == 4 &&
           (d->in_mode == DDPM3D_IN_SAME || d->in_mode == DDPM3D_IN_UP)))

@@ -59,14 +59,18 @@ __device__ __forceinline__ void quad_transpose(float (&a)[4], bool b0, bool b1) 
 // row = (reg&3) + 8*(reg>>2) + 4*half.
 // inv_act = 1 / activation scale of this sample (split-f16 modes; 1 in the exact mode)
 template <int PREC, int WM, int MT, int TXL, int TYL>
+// pre_ws / pre_bias (pre = true): p.wscale[cout] and the lane's bias, loaded by the caller at kernel
+// START (conv3d_wz.h): at the epilogue's start they are a dependent global load -- ~2k cycles at the
+// head of a phase in which the wave issues no MFMA
 __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc)[MT], int n, int z0, int y0,
                                               int x0, int tile_in_n, int wm, int cout, int half, int ksplit_idx,
-                                              float inv_act) {
+                                              float inv_act, bool pre = false, float pre_ws = 1.0f,
+                                              float pre_bias = 0.0f) {
     constexpr int TX = 1 << TXL, TY = 1 << TYL;
     const bool cvalid = cout < p.Cout;
     const size_t DHW = (size_t)p.D * p.H * p.W;
     // PREC 1/2: undo the operand scaling (exact: a power of two per cout)
-    const float oscale = (PREC != 0 && cvalid) ? p.wscale[cout] * inv_act : 1.0f;
+    const float oscale = (PREC != 0 && cvalid) ? (pre ? pre_ws : p.wscale[cout]) * inv_act : 1.0f;
 
     // Fast path -- every launch of the network except ragged edge tiles, the NCDHW output conv
     // and the up/down-sampling skip sums: the tile lies inside the volume, so element (t, reg)
@@ -136,7 +140,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 const unsigned cq = (unsigned)(cout & ~3);
                 const unsigned wv = cvalid ? lane_vox * cstride + cq * eso : DDPM3D_OOB_OFFSET;
                 const unsigned wr = cvalid ? lane_vox * rstride + cq * esr : DDPM3D_OOB_OFFSET;
-                const float bias_w = (!split && cvalid) ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
+                const float bias_w = (!split && cvalid) ? (pre ? pre_bias : p.bias[(size_t)n * p.bias_stride_n + cout]) : 0.0f;
                 double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
@@ -197,7 +201,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 return;
             }
             roff_ = cvalid ? rbase : DDPM3D_OOB_OFFSET;
-            const float bias = (!split && cvalid) ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
+            const float bias = (!split && cvalid) ? (pre ? pre_bias : p.bias[(size_t)n * p.bias_stride_n + cout]) : 0.0f;
             double s1 = 0.0, s2 = 0.0;   // GroupNorm partial sums in fp64 (gn_sums_add below)
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
@@ -280,7 +284,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
         }
         return;
     }
-    const float bias = cvalid ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
+    const float bias = cvalid ? (pre ? pre_bias : p.bias[(size_t)n * p.bias_stride_n + cout]) : 0.0f;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {

@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     }
 
     const int cout = wg.cy * 128 + wn * 32 + (lane & 31);
+    // the epilogue's per-cout scale and bias, requested now (two registers for the kernel's life)
+    const float pre_ws = cout < p.Cout ? p.wscale[cout] : 1.0f;
+    const float pre_bias = cout < p.Cout ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
     const __amdgpu_buffer_rsrc_t wrsrc = make_rsrc(p.w, p.w_bytes);
     const unsigned wlane = ((unsigned)cout * 2 + half) * 16;
     const unsigned wpart = (unsigned)p.CoutPad * 32;
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         outv[2 + t] = acc[1][t] - acc[2][t] - acc[3][t];
     }
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<1, 1, 4, TXL, TYL>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split, asc.inv);
+    conv_epilogue<1, 1, 4, TXL, TYL>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split, asc.inv, true, pre_ws,
+                                     pre_bias);
 #ifdef DDPM3D_WZ_STAMPS
     WZ_STAMP(43);
     if (lane == 0) {

@@ -212,6 +212,18 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(
     const int cs = from0 ? cbeg : cbeg - C0;
     // statistics are channel-major [N][C][rows][2] fp64: the group's cg channels x rows partial sums
     // are ONE contiguous, 16-byte aligned run of cg*rows (sum, sum of squares) pairs
+    // the affine's inputs do not depend on the statistics: requested FIRST, so that their latency runs
+    // beside the partial-sum loads' instead of behind the reduction (one dependent round trip less)
+    const int c_own = cbeg + (int)(threadIdx.x < (unsigned)cg ? threadIdx.x : 0);
+    float g_own = 0.0f, b_own = 0.0f, sc_own = 1.0f, sh_own = 0.0f;
+    if (gamma != nullptr) {
+        g_own = gamma[c_own];
+        b_own = beta[c_own];
+        if (film != nullptr) {
+            sc_own = 1.0f + film[(size_t)n * film_stride + film_off + c_own];
+            sh_own = film[(size_t)n * film_stride + film_off + C + c_own];
+        }
+    }
     double s1 = 0.0, s2 = 0.0;
     float m2 = 0.0f;                                  // largest sum of squares of any row of the group
     const size_t items = (size_t)rows * cg;          // double2 count
@@ -258,11 +270,12 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(
     float amax = 0.0f, bmax = 0.0f;
     for (int c = threadIdx.x; c < cg; c += blockDim.x) {
         const int ch = cbeg + c;
-        float a = rstd * gamma[ch];
-        float b = fmaf(-meanf, a, beta[ch]);
+        const bool own = c == (int)threadIdx.x;       // (cg <= blockDim.x: every channel is some thread's own)
+        float a = rstd * (own ? g_own : gamma[ch]);
+        float b = fmaf(-meanf, a, own ? b_own : beta[ch]);
         if (film != nullptr) {
-            const float sc = 1.0f + film[(size_t)n * film_stride + film_off + ch];
-            const float sh = film[(size_t)n * film_stride + film_off + C + ch];
+            const float sc = own ? sc_own : 1.0f + film[(size_t)n * film_stride + film_off + ch];
+            const float sh = own ? sh_own : film[(size_t)n * film_stride + film_off + C + ch];
             a = a * sc;
             b = fmaf(b, sc, sh);
         }

@@ -30,6 +30,7 @@ IO_SRC0_BF16, IO_SRC1_BF16, IO_OUT_BF16, IO_RES_BF16 = 1, 2, 4, 8
 ABI_VERSION = 10
 # ddpm3d_conv_desc.kernel_hint bits (launch orders of identical arithmetic; tests and A/B measurements)
 HINT_WSTAT_OFF, HINT_WSTAT_ON = 0x100, 0x200
+HINT_SPLITK_SHIFT = 16      # bits 16..21: forced split factor (measurement only, tools/splitk_sweep.py)
 HINT_WZ_ORDER_SHIFT = 12     # bits 12..14: tap issue order of the f16x3 Winograd-D kernel (A/B measurements)
 
 _fp = C.c_void_p

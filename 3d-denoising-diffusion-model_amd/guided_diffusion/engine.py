@@ -260,6 +260,9 @@ class _Plan:
         # bf16 mode: the residual stream (every tensor a conv writes and convs read) is stored in
         # bf16; tensors read by the fp32-only kernels (attention, subsample, gn_stats) stay fp32
         self.bf16 = eng.precision == "bf16"
+        # only the split-f16 arithmetic scales its operands from in_bound (api.hip: prec_scaled); the exact
+        # and the bf16 plans enqueue neither the input-range pass nor bound-only finalizes
+        self.scaled = eng.precision in ("f16x3", "f16")
 
         def new_act(Cn, d, h, w, fp32=False):
             # the statistics buffer is attached by the conv step that produces the tensor
@@ -291,7 +294,8 @@ class _Plan:
             # range of the two input volumes (they carry no statistics): [N][2] = max |x|, max |low_res|
             self.in_absmax = torch.empty(N * 2, dtype=torch.float32, device=dev)
             self.absmax_args = [0, 0, N, D * Hh * W, H.ptr(self.in_absmax), 0]
-            self.steps.append((lib.ddpm3d_absmax, self.absmax_args))
+            if self.scaled:
+                self.steps.append((lib.ddpm3d_absmax, self.absmax_args))
             self.first_desc = self.conv_step(cin_conv, srcs=None, out=h, planar=True,
                                              bound=(self.in_absmax, 0, 2, 1))
         else:
@@ -301,7 +305,8 @@ class _Plan:
             self.in_absmax = torch.empty(N, dtype=torch.float32, device=dev)
             self.absmax_args = [0, 0, N, ci * D * Hh * W, H.ptr(self.in_absmax), 0]
             self.pad_args = [0, N, ci, D * Hh * W, eng.cin_pad, H.ptr(xin.buf), 0]
-            self.steps.append((lib.ddpm3d_absmax, self.absmax_args))
+            if self.scaled:
+                self.steps.append((lib.ddpm3d_absmax, self.absmax_args))
             self.steps.append((lib.ddpm3d_ncdhw_to_ndhwc_pad, self.pad_args))
             self.first_desc = self.conv_step(cin_conv, srcs=[xin], out=h, bound=(self.in_absmax, 0, 1, 1))
         hs = [h]
@@ -339,11 +344,14 @@ class _Plan:
                 dsc.workspace, dsc.workspace_bytes = H.ptr(self.workspace), self.ws_bytes
 
     # ---- helpers -------------------------------------------------------------
-    def finalize(self, srcs, gn_prefix, film_prefix):
+    def finalize(self, srcs, gn_prefix, film_prefix, need_bound=None):
         """gn_finalize over the virtual concat of `srcs`; returns (A, B, bound) tensors.  bound =
         [N][32][2]: upper bounds of |act(A*x + B)| (entry 0) and of |x| (entry 1) per group, the
-        in_bound of the convs that read the tensor normalised / raw.  gn_prefix None: bounds only."""
+        in_bound of the convs that read the tensor normalised / raw.  gn_prefix None: bounds only
+        (no launch at all when nothing reads them: exact / bf16 plans, unless need_bound)."""
         eng, N = self.eng, self.N
+        if gn_prefix is None and not (self.scaled if need_bound is None else need_bound):
+            return None, None, None
         Cn = sum(s.C for s in srcs)
         A = torch.empty(N * Cn, dtype=torch.float32, device=eng.device) if gn_prefix else None
         B = torch.empty(N * Cn, dtype=torch.float32, device=eng.device) if gn_prefix else None
@@ -416,10 +424,11 @@ class _Plan:
         io |= H.IO_OUT_BF16 if (out is not None and out.bf16) else 0
         io |= H.IO_RES_BF16 if (res is not None and res.bf16) else 0
         d.io_dtype = io
-        if bound is None:
-            raise RuntimeError("conv_step without an input bound")
-        d.in_bound = bound[0].data_ptr() + 4 * bound[1]
-        d.in_bound_count, d.in_bound_stride = bound[2], bound[3]
+        if self.scaled:
+            if bound is None or bound[0] is None:
+                raise RuntimeError("conv_step without an input bound")
+            d.in_bound = bound[0].data_ptr() + 4 * bound[1]
+            d.in_bound_count, d.in_bound_stride = bound[2], bound[3]
         if (pc.wz is not None and not planar and in_mode in (H.IN_SAME, H.IN_UP)
                 and d.H >= 8 and d.W >= 8):
             pc_use = pc.wz       # Winograd-D form: same layer, same arithmetic, 2/3 of the MFMAs
@@ -500,7 +509,8 @@ class _Plan:
         self.conv_step(eng.conv[p + ".qkv"], [x], qkv, aff=(A, B), act=H.ACT_NONE, bound=(bnd, 0, 32, 2))
         # range of q, k, v (and of the attention output, a convex combination of v) from qkv's
         # own partial sums
-        _, _, qb = self.finalize([qkv], None, None)
+        # (the bf16 plan keeps this one: its attention products run in the f16x3 arithmetic)
+        _, _, qb = self.finalize([qkv], None, None, need_bound=eng.precision != "f32")
         a = self.new_act(Cn, x.D, x.H, x.W, fp32=True)
         # two T x T x ch products per head (the reference's count_flops_attn, unet.py:308-325)
         self.conv_meta[len(self.steps)] = ("attention_ch%d" % ch, 4.0 * N * heads * float(x.voxels) ** 2 * ch)
@@ -509,7 +519,7 @@ class _Plan:
         # fp32 (unet.py:351), and f16-rounded scores would cost more accuracy than the convs do)
         aprec = H.PREC_F32 if eng.precision == "f32" else H.PREC_F16X3   # (bf16 mode too: fp32-grade scores)
         self.steps.append((eng.lib.ddpm3d_attention_p,
-                           [H.ptr(qkv.buf), N, x.voxels, heads, ch, aprec, H.ptr(qb) + 4, 32, 2, H.ptr(a.buf), 0]))
+                           [H.ptr(qkv.buf), N, x.voxels, heads, ch, aprec, (H.ptr(qb) + 4) if qb is not None else 0, 32, 2, H.ptr(a.buf), 0]))
         self.release(qkv)
         y = self.new_act(Cn, x.D, x.H, x.W)
         self.conv_step(eng.conv[p + ".proj_out"], [a], y, res=x, res_mode=H.RES_SAME, bound=(qb, 1, 32, 2))

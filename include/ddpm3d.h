@@ -160,7 +160,11 @@ enum {
     /* bits 12..14: issue order of a tap in the f16x3 Winograd-D kernel (conv3d_wz.h, IL + 1; 0 = the
      * library picks by shape) */
     DDPM3D_HINT_WZ_ORDER_SHIFT = 12,
-    DDPM3D_HINT_WZ_ORDER_MASK = 0x7000
+    DDPM3D_HINT_WZ_ORDER_MASK = 0x7000,
+    /* bits 16..21: force the split factor over Cin of a 3x3x3 conv (measurement only: no statistics,
+     * workspace sized by the caller as S * output bytes; 0 = the library's own choice) */
+    DDPM3D_HINT_SPLITK_SHIFT = 16,
+    DDPM3D_HINT_SPLITK_MASK = 0x3F0000
 };
 
 int ddpm3d_abi_version(void);

@@ -117,7 +117,9 @@ def test_c4_ddim50_published_bf16_mode_psnr():
     mse = float(((out - ref) ** 2).mean())
     psnr = 10 * np.log10(4.0 / max(mse, 1e-30))
     print("config 4 (ddim50, bf16 operands + bf16 residual stream) PSNR vs f16x3: %.1f dB" % psnr)
-    assert psnr > 30.0, psnr            # measured 36.6 dB
+    # PARITY UNPINNED against the reference (it has fp16 only; no fixture covers bf16): the bar is this
+    # package's own fp32-grade run.  Measured 36.6 dB; 34 dB catches a regression of a few dB.
+    assert psnr > 34.0, psnr
 
 
 def test_c5_full_size_attention_forward_properties():

@@ -235,6 +235,36 @@ def test_conv3d_bf16_mode(hc, precision, N, D, Hh, W, ci, co):
     assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(xi, wi, bi, padding=1))
 
 
+@pytest.mark.parametrize("N,D,Hh,W,ci,co,k", [
+    (1, 4, 16, 16, 64, 128, 3),     # direct form, 8x8 tiles
+    (1, 8, 4, 4, 256, 128, 3),      # 4x4 tiles, split over Cin (slabs + reduce kernel)
+    (2, 3, 8, 8, 96, 64, 1),        # 1x1 conv
+    (1, 6, 16, 16, 64, 2, 3),       # the last-layer kernel (conv3d_skinny.hip)
+])
+def test_conv3d_bf16_mode_vs_bf16_rounded_operands(hc, N, D, Hh, W, ci, co, k):
+    """the bf16 mode has no counterpart in the reference (fp16 only), so it is PARITY
+    UNPINNED against it; what CAN be pinned is the arithmetic it claims -- the fp32-activated input and
+    the weights each rounded ONCE to bf16, exact products, fp32 accumulation.  Every direct-form path
+    (8x8 tiles, 4x4 tiles with split-K, 1x1, the last-layer kernel) against torch's fp32 conv on those
+    rounded operands, at the fp32 bar per output channel.  (The Winograd-D form rounds the TRANSFORMED
+    operands instead and is held to the half-precision bar in test_conv3d_bf16_mode.)"""
+    import guided_diffusion._hip as H
+    x = rnd(N, ci, D, Hh, W, seed=61) * 3.0
+    w = rnd(co, ci, k, k, k, seed=62, scale=0.05)
+    b = rnd(co, seed=63)
+    A = 1.0 + 0.1 * rnd(N, ci, seed=64)
+    B = 0.1 * rnd(N, ci, seed=65)
+    xa = F.silu(x * A[:, :, None, None, None] + B[:, :, None, None, None])
+    ref = F.conv3d(xa.bfloat16().float().double(), w.bfloat16().float().double(), b.double(), padding=k // 2).float()
+    kw = dict(out_layout=H.OUT_NCDHW, want_stats=False) if co <= 2 else {}
+    out, _, _ = hc.conv3d([hc.to_ndhwc(x).cuda()], w.cuda(), b.cuda(), (D, Hh, W), aff=(A.cuda(), B.cuda()),
+                          act=H.ACT_SILU, precision=5, **kw)
+    got = out.cpu() if co <= 2 else hc.to_ncdhw(out.cpu())
+    # (the kernel's SiLU uses v_exp / v_rcp, ~2 ulp: a value that lands on the other side of a bf16
+    # rounding boundary moves one product by 2^-8 -- a handful of such flips per output)
+    assert rel_err_per_channel(got.numpy(), ref.numpy()) < 2e-4
+
+
 @pytest.mark.parametrize("precision", [0, 3, 5, 6])
 def test_conv3d_bf16_tensors(hc, precision):
     """ddpm3d_conv_desc.io_dtype: sources (virtual concat of a bf16 and an fp32 tensor), residual and
