@@ -141,10 +141,11 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     k.reduce_vox = c.reduce_vox;
     k.hint = d->kernel_hint;
     k.io = d->io_dtype;
-    if (d->io_dtype & ~(DDPM3D_IO_SRC0_BF16 | DDPM3D_IO_SRC1_BF16 | DDPM3D_IO_OUT_BF16 | DDPM3D_IO_RES_BF16))
+    if (d->io_dtype & ~(DDPM3D_IO_SRC0_BF16 | DDPM3D_IO_SRC1_BF16 | DDPM3D_IO_OUT_BF16 | DDPM3D_IO_RES_BF16 |
+                        DDPM3D_IO_HALF_IS_F16))
         return fail(DDPM3D_EINVAL, "conv3d: unknown io_dtype bits %#x", d->io_dtype);
     if ((d->io_dtype & DDPM3D_IO_OUT_BF16) && d->out_layout != DDPM3D_OUT_NDHWC)
-        return fail(DDPM3D_EINVAL, "conv3d: a bf16 output needs the NDHWC layout");
+        return fail(DDPM3D_EINVAL, "conv3d: a 16-bit output needs the NDHWC layout");
     if ((d->io_dtype & (DDPM3D_IO_SRC0_BF16 | DDPM3D_IO_SRC1_BF16)) && d->in_mode == DDPM3D_IN_PLANAR2)
         return fail(DDPM3D_EINVAL, "conv3d: the planar input volumes are fp32");
     if (prec_scaled(d->precision)) {
@@ -192,7 +193,8 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     // one or two output channels (the network's last layer): its own kernel (conv3d_skinny.hip)
     if (d->ksize == 3 && d->Cout <= 2 && d->in_mode == DDPM3D_IN_SAME && d->C1 == 0 && !d->stats &&
         d->res_mode == DDPM3D_RES_NONE &&
-        ddpm3d_skinny_ok(k.CinPad, d->precision, (d->io_dtype & DDPM3D_IO_SRC0_BF16) != 0))
+        ddpm3d_skinny_ok(k.CinPad, d->precision, !(d->io_dtype & DDPM3D_IO_SRC0_BF16) ? 0
+                                                  : ((d->io_dtype & DDPM3D_IO_HALF_IS_F16) ? 2 : 1)))
         return launched(ddpm3d_launch_conv_skinny(k, d->precision, (hipStream_t)stream), "conv3d (skinny)");
     const int rc = launched(ddpm3d_launch_conv(k, c, (hipStream_t)stream), "conv3d");
     if (rc != DDPM3D_OK || c.S == 1) return rc;

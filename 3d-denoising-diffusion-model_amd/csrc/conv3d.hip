@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, (PIPEM == 2 ? 1 : (TXL == 2 ? 2 : 3))) void co
                         const int hy = rem / HX;
                         const int hx = rem - hy * HX;
                         const bool inb = halo_inb(p, z0 - PAD + hz, y0 - PAD + hy, x0 - PAD + hx);
-                        store_item(hz, hy, hx, halo_finish<PREC != 0>(hs, quad_bits_expand(raw[i], hs.b16), inb, act_mask));
+                        store_item(hz, hy, hx, halo_finish<PREC != 0>(hs, quad_bits_expand(raw[i], hs.b16, hs.f16), inb, act_mask));
                     }
                 }
             } else {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) 
                 val += ddpm3d_residual(p, n, z, y, x, cout);
             }
             if (p.out_layout == DDPM3D_OUT_NDHWC)
-                ddpm3d_act_store(p.out, e, val, (p.io & DDPM3D_IO_OUT_BF16) != 0);
+                ddpm3d_act_store(p.out, e, val, (p.io & DDPM3D_IO_OUT_BF16) != 0, (p.io & DDPM3D_IO_HALF_IS_F16) != 0);
             else
                 p.out[((size_t)n * p.Cout + cout) * DHW + v] = val;
             gn_sums_add(s1, s2, val);
@@ -397,9 +397,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK 
 #pragma unroll
                         for (int c = 0; c < 4; ++c) val[c] += ddpm3d_residual(p, n, z, y, x, q * 4 + c);
                     }
-                    if (p.io & DDPM3D_IO_OUT_BF16)
+                    if (p.io & DDPM3D_IO_OUT_BF16) {
+                        const bool f16 = (p.io & DDPM3D_IO_HALF_IS_F16) != 0;
                         *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + e) =
-                            u32x2{bf16_pack(val[0], val[1]), bf16_pack(val[2], val[3])};
+                            u32x2{half_pack(val[0], val[1], f16), half_pack(val[2], val[3], f16)};
+                    }
                     else
                         *reinterpret_cast<f32x4*>(p.out + e) = val;
 #pragma unroll

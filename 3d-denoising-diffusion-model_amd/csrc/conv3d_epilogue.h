@@ -92,6 +92,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
         const size_t samp_r = (size_t)p.D * Hr * Wr * p.Cout;
         // bf16 tensors (ddpm3d_conv_desc.io_dtype): 2-byte elements, same offsets in elements
         const bool o16 = !split && (p.io & DDPM3D_IO_OUT_BF16), r16 = (p.io & DDPM3D_IO_RES_BF16) != 0;
+        const bool f16 = (p.io & DDPM3D_IO_HALF_IS_F16) != 0;      // the 16-bit tensors hold IEEE f16, not bf16
         const unsigned eso = o16 ? 2u : 4u, esr = r16 ? 2u : 4u;
         if (full && p.out_layout == DDPM3D_OUT_NDHWC && samp_r * 4 < 0xFFFFFFF0ull) {
             const size_t samp = DHW * p.Cout;                       // elements per sample (< 2^30, C ABI guard)
@@ -122,7 +123,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
             unsigned roff_ = 0;
             // one element of the residual at lane base + scalar offset
             auto rload = [&](const unsigned so) {
-                if (r16) return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rrsrc, roff_, so, 0) << 16);
+                if (r16) return ddpm3d_half_to_float((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rrsrc, roff_, so, 0), f16);
                 return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff_, so, 0));
             };
             // ---- WIDE form (r03): residual none / same and Cout % 4 == 0 -- every such launch of the network.
@@ -151,7 +152,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                             const int m0 = (wm * MT + t) * 32 + 8 * g;
                             const int ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL), tx = m0 & (TX - 1);
                             const unsigned so = (unsigned)((tz * p.H + ty) * p.W + tx) * rstride;
-                            if (r16) rq[g] = bf16x4_expand(__builtin_amdgcn_raw_buffer_load_b64(rrsrc, wr, so, 0));
+                            if (r16) rq[g] = half4_expand(__builtin_amdgcn_raw_buffer_load_b64(rrsrc, wr, so, 0), f16);
                             else rq[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, wr, so, 0));
                         }
                     }
@@ -175,7 +176,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                         const int ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL), tx = m0 & (TX - 1);
                         const unsigned so = (unsigned)((tz * p.H + ty) * p.W + tx) * cstride;
                         if (o16)
-                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{bf16_pack(a[0], a[1]), bf16_pack(a[2], a[3])}, drsrc, wv, so, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{half_pack(a[0], a[1], f16), half_pack(a[2], a[3], f16)}, drsrc, wv, so, 0);
                         else
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]),
                                                                          __builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])},
@@ -248,7 +249,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                         gn_sums_add(s1, s2, val);
                     }
                     if (o16)
-                        __builtin_amdgcn_raw_buffer_store_b16(ddpm3d_to_bf16(val), drsrc, voff, soff[reg], 0);
+                        __builtin_amdgcn_raw_buffer_store_b16(ddpm3d_to_half(val, f16), drsrc, voff, soff[reg], 0);
                     else
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), drsrc, voff, soff[reg], 0);
                 }
@@ -300,7 +301,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 const size_t vox = ((size_t)z * p.H + y) * p.W + x;
                 if (p.res_mode != DDPM3D_RES_NONE) val += ddpm3d_residual(p, n, z, y, x, cout);
                 if (p.out_layout == DDPM3D_OUT_NDHWC)
-                    ddpm3d_act_store(p.out, ((size_t)n * DHW + vox) * p.Cout + cout, val, (p.io & DDPM3D_IO_OUT_BF16) != 0);
+                    ddpm3d_act_store(p.out, ((size_t)n * DHW + vox) * p.Cout + cout, val, (p.io & DDPM3D_IO_OUT_BF16) != 0,
+                                     (p.io & DDPM3D_IO_HALF_IS_F16) != 0);
                 else
                     p.out[((size_t)n * p.Cout + cout) * DHW + vox] = val;
                 gn_sums_add(s1, s2, val);

@@ -34,6 +34,10 @@ __device__ __forceinline__ f32x4 affine_act(f32x4 v, f32x4 a, f32x4 b) {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// The 16-bit storage of an activation tensor (ddpm3d_conv_desc.io_dtype): bf16, or -- with
+// DDPM3D_IO_HALF_IS_F16, the reference's own --use_fp16 storage (unet.py:1035, fp16_util.py:15-22) --
+// IEEE f16.  `f16` is launch-uniform everywhere below.
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 // four bf16 (two dwords) -> four fp32
 __device__ __forceinline__ f32x4 bf16x4_expand(u32x2 v) {
     f32x4 r;
@@ -49,15 +53,28 @@ __device__ __forceinline__ unsigned bf16_pack(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
-// quad q4 (4 channels starting at element offset e) of an fp32 or bf16 activation tensor
-__device__ __forceinline__ f32x4 act_quad(const float* base, size_t e, bool bf16) {
-    if (bf16) return bf16x4_expand(*reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + e));
+// four f16 (two dwords) -> four fp32 (exact)
+__device__ __forceinline__ f32x4 f16x4_expand(u32x2 v) {
+    return __builtin_convertvector(__builtin_bit_cast(h4v, v), f32x4);
+}
+// two fp32 -> packed f16 pair (round to nearest even; beyond 65504 -> inf, as torch's .half())
+__device__ __forceinline__ unsigned f16_pack(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ f32x4 half4_expand(u32x2 v, bool f16) { return f16 ? f16x4_expand(v) : bf16x4_expand(v); }
+__device__ __forceinline__ unsigned half_pack(float lo, float hi, bool f16) { return f16 ? f16_pack(lo, hi) : bf16_pack(lo, hi); }
+// quad q4 (4 channels starting at element offset e) of an fp32 or 16-bit activation tensor
+__device__ __forceinline__ f32x4 act_quad(const float* base, size_t e, bool b16, bool f16) {
+    if (b16) return half4_expand(*reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + e), f16);
     return *reinterpret_cast<const f32x4*>(base + e);
 }
 
 struct HaloSrc {
     const float* src;  // source tensor of this chunk (after the concat split)
-    bool b16;          // it holds bf16 elements (ddpm3d_conv_desc.io_dtype)
+    bool b16;          // it holds 16-bit elements (ddpm3d_conv_desc.io_dtype) ...
+    bool f16;          // ... which are IEEE f16 rather than bf16
     unsigned src_bytes;  // its extent (buffer descriptor num_records)
     int Cs;            // its channel count
     int cb;            // first channel of the chunk inside it
@@ -73,6 +90,7 @@ __device__ __forceinline__ HaloSrc halo_src(const ConvK& p, int n, int chunk, in
     const bool from0 = c0 < p.C0;
     h.src = from0 ? p.src0 : p.src1;
     h.b16 = (p.io & (from0 ? DDPM3D_IO_SRC0_BF16 : DDPM3D_IO_SRC1_BF16)) != 0;
+    h.f16 = (p.io & DDPM3D_IO_HALF_IS_F16) != 0;
     h.src_bytes = from0 ? p.src0_bytes : p.src1_bytes;
     h.Cs = from0 ? p.C0 : p.C1;
     h.cb = from0 ? c0 : c0 - p.C0;
@@ -97,7 +115,7 @@ __device__ __forceinline__ f32x4 halo_fetch(const ConvK& p, const HaloSrc& h, in
         // (y, x) are coordinates of the SOURCE grid here (the strided conv's halo is laid out in it)
         if (!((unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)h.Hs && (unsigned)x < (unsigned)h.Ws)) return v;
         const size_t vox = (((size_t)n * p.D + z) * h.Hs + y) * h.Ws + x;
-        v = act_quad(h.src, vox * h.Cs + h.cb + q * 4, h.b16);
+        v = act_quad(h.src, vox * h.Cs + h.cb + q * 4, h.b16, h.f16);
         if (h.has_aff) v = p.act ? affine_act<1, FAST>(v, h.ga, h.gb) : affine_act<0, FAST>(v, h.ga, h.gb);
         return v;
     }
@@ -105,20 +123,20 @@ __device__ __forceinline__ f32x4 halo_fetch(const ConvK& p, const HaloSrc& h, in
     if (!inb) return v;
     if (p.in_mode == DDPM3D_IN_SAME) {
         const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
-        v = act_quad(h.src, vox * h.Cs + h.cb + q * 4, h.b16);
+        v = act_quad(h.src, vox * h.Cs + h.cb + q * 4, h.b16, h.f16);
         if (h.has_aff) v = p.act ? affine_act<1, FAST>(v, h.ga, h.gb) : affine_act<0, FAST>(v, h.ga, h.gb);
     } else if (p.in_mode == DDPM3D_IN_UP) {
         const size_t vox = (((size_t)n * p.D + z) * h.Hs + (y >> 1)) * h.Ws + (x >> 1);
-        v = act_quad(h.src, vox * h.Cs + h.cb + q * 4, h.b16);
+        v = act_quad(h.src, vox * h.Cs + h.cb + q * 4, h.b16, h.f16);
         if (h.has_aff) v = p.act ? affine_act<1, FAST>(v, h.ga, h.gb) : affine_act<0, FAST>(v, h.ga, h.gb);
     } else if (p.in_mode == DDPM3D_IN_POOL) {
         // AvgPool3d window order (h, w): ((s00 + s01) + s10) + s11, then * 1/4
         const size_t vox = (((size_t)n * p.D + z) * h.Hs + 2 * y) * h.Ws + 2 * x;
         const size_t e0 = vox * h.Cs + h.cb + q * 4;
-        f32x4 s00 = act_quad(h.src, e0, h.b16);
-        f32x4 s01 = act_quad(h.src, e0 + h.Cs, h.b16);
-        f32x4 s10 = act_quad(h.src, e0 + (size_t)h.Ws * h.Cs, h.b16);
-        f32x4 s11 = act_quad(h.src, e0 + (size_t)h.Ws * h.Cs + h.Cs, h.b16);
+        f32x4 s00 = act_quad(h.src, e0, h.b16, h.f16);
+        f32x4 s01 = act_quad(h.src, e0 + h.Cs, h.b16, h.f16);
+        f32x4 s10 = act_quad(h.src, e0 + (size_t)h.Ws * h.Cs, h.b16, h.f16);
+        f32x4 s11 = act_quad(h.src, e0 + (size_t)h.Ws * h.Cs + h.Cs, h.b16, h.f16);
         if (h.has_aff) {
             if (p.act) {
                 s00 = affine_act<1, FAST>(s00, h.ga, h.gb); s01 = affine_act<1, FAST>(s01, h.ga, h.gb);
@@ -170,8 +188,8 @@ __device__ __forceinline__ u32x4 buffer_load_quad(__amdgpu_buffer_rsrc_t r, unsi
     }
     return buffer_load16(r, voff, soff);
 }
-__device__ __forceinline__ f32x4 quad_bits_expand(u32x4 bits, bool b16) {
-    return b16 ? bf16x4_expand(u32x2{bits[0], bits[1]}) : __builtin_bit_cast(f32x4, bits);
+__device__ __forceinline__ f32x4 quad_bits_expand(u32x4 bits, bool b16, bool f16 = false) {
+    return b16 ? half4_expand(u32x2{bits[0], bits[1]}, f16) : __builtin_bit_cast(f32x4, bits);
 }
 
 // Voxel index (in the SOURCE tensor's D x Hs x Ws grid) of a halo item, or -1 outside the

@@ -156,7 +156,7 @@ static inline hipError_t ddpm3d_allow_dynamic_lds(DynLdsOnce& done, const void* 
 hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st);
 hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st);
 hipError_t ddpm3d_launch_conv_skinny(const ConvK& k, int prec, hipStream_t st);   // conv3d_skinny.hip
-bool ddpm3d_skinny_ok(int CinPad, int prec, bool src_bf16);
+bool ddpm3d_skinny_ok(int CinPad, int prec, int src16);   // src16: 0 fp32, 1 bf16, 2 f16
 
 // GroupNorm partial sums are accumulated and stored in fp64 (r03).  With fp32 sums the variance
 // E[x^2] - mean^2 loses |mean|^2 / var x 1e-7 of its value to cancellation -- invisible on
@@ -171,39 +171,48 @@ __device__ __forceinline__ void gn_sums_add(double& s1, double& s2, float val) {
 
 // Residual term of the conv epilogue for output element (n, z, y, x, cout);
 // shared by the conv kernel and the split-K reduce kernel.
-// element e of an activation tensor that holds fp32 or (bf16 = true) bf16 values
-__device__ __forceinline__ float ddpm3d_act_load(const float* base, size_t e, bool bf16) {
-    if (bf16) return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(base)[e] << 16);
+// element e of an activation tensor that holds fp32 or (b16) 16-bit values: bf16, or (f16) IEEE f16
+__device__ __forceinline__ float ddpm3d_half_to_float(unsigned short h, bool f16) {
+    if (f16) return (float)__builtin_bit_cast(_Float16, h);
+    return __builtin_bit_cast(float, (unsigned)h << 16);
+}
+__device__ __forceinline__ float ddpm3d_act_load(const float* base, size_t e, bool b16, bool f16) {
+    if (b16) return ddpm3d_half_to_float(reinterpret_cast<const unsigned short*>(base)[e], f16);
     return base[e];
 }
 // fp32 -> bf16, round to nearest even, NaN stays NaN (hipcc lowers the cast to v_cvt_pk_bf16_f32)
 __device__ __forceinline__ unsigned short ddpm3d_to_bf16(float v) {
     return __builtin_bit_cast(unsigned short, (__bf16)v);
 }
-__device__ __forceinline__ void ddpm3d_act_store(float* base, size_t e, float v, bool bf16) {
-    if (bf16) reinterpret_cast<unsigned short*>(base)[e] = ddpm3d_to_bf16(v);
+// fp32 -> the tensor's 16-bit type, round to nearest even
+__device__ __forceinline__ unsigned short ddpm3d_to_half(float v, bool f16) {
+    if (f16) return __builtin_bit_cast(unsigned short, (_Float16)v);
+    return ddpm3d_to_bf16(v);
+}
+__device__ __forceinline__ void ddpm3d_act_store(float* base, size_t e, float v, bool b16, bool f16) {
+    if (b16) reinterpret_cast<unsigned short*>(base)[e] = ddpm3d_to_half(v, f16);
     else base[e] = v;
 }
 
 __device__ __forceinline__ float ddpm3d_residual(const ConvK& p, int n, int z, int y, int x, int cout) {
-    const bool b16 = (p.io & DDPM3D_IO_RES_BF16) != 0;
+    const bool b16 = (p.io & DDPM3D_IO_RES_BF16) != 0, f16 = (p.io & DDPM3D_IO_HALF_IS_F16) != 0;
     if (p.res_mode == DDPM3D_RES_SAME) {
         const size_t vox = (((size_t)n * p.D + z) * p.H + y) * p.W + x;
-        return ddpm3d_act_load(p.res, vox * p.Cout + cout, b16);
+        return ddpm3d_act_load(p.res, vox * p.Cout + cout, b16, f16);
     }
     if (p.res_mode == DDPM3D_RES_UP) {
         const int Hr = p.H / 2, Wr = p.W / 2;
         const size_t rv = (((size_t)n * p.D + z) * Hr + (y >> 1)) * Wr + (x >> 1);
-        return ddpm3d_act_load(p.res, rv * p.Cout + cout, b16);
+        return ddpm3d_act_load(p.res, rv * p.Cout + cout, b16, f16);
     }
     if (p.res_mode == DDPM3D_RES_POOL) {
         // AvgPool3d window order (h, w): ((r00 + r01) + r10) + r11, then * 1/4
         const int Hr = p.H * 2, Wr = p.W * 2;
         const size_t rv = (((size_t)n * p.D + z) * Hr + 2 * y) * Wr + 2 * x;
         const size_t e = rv * p.Cout + cout;
-        const float r = ((ddpm3d_act_load(p.res, e, b16) + ddpm3d_act_load(p.res, e + p.Cout, b16)) +
-                         ddpm3d_act_load(p.res, e + (size_t)Wr * p.Cout, b16)) +
-                        ddpm3d_act_load(p.res, e + (size_t)Wr * p.Cout + p.Cout, b16);
+        const float r = ((ddpm3d_act_load(p.res, e, b16, f16) + ddpm3d_act_load(p.res, e + p.Cout, b16, f16)) +
+                         ddpm3d_act_load(p.res, e + (size_t)Wr * p.Cout, b16, f16)) +
+                        ddpm3d_act_load(p.res, e + (size_t)Wr * p.Cout + p.Cout, b16, f16);
         return r * 0.25f;
     }
     return 0.0f;

@@ -30,7 +30,7 @@ constexpr int SK_PSTRIDE = SK_COLS + 1;                          // P row stride
 #endif
 
 // one plane of a lane's halo voxel: per k-step its 8 channels (two 16-byte quads of fp32, or one of bf16)
-template <int NCH, bool B16>
+template <int NCH, int B16>
 __device__ __forceinline__ void sk_issue(__amdgpu_buffer_rsrc_t rs, unsigned vo, unsigned soff_, u32x4 (&raw)[NCH][2]) {
     // (forced uniform: the compiler keeps it in a VGPR otherwise and wraps every load in a waterfall loop)
     const unsigned soff = __builtin_amdgcn_readfirstlane(soff_);
@@ -45,7 +45,7 @@ __device__ __forceinline__ void sk_issue(__amdgpu_buffer_rsrc_t rs, unsigned vo,
 // NCH = Cin / 16 and B16 (bf16 source tensor) are compile-time: with run-time tests per k-step the
 // compiler split the plane loop into blocks joined by 64 accumulator copies each and selected the
 // element type per value -- as many instructions again as the arithmetic.
-template <int MODE, int NCH, bool B16>
+template <int MODE, int NCH, int B16>
 __global__ __launch_bounds__(256, 2) void conv3d_skinny_kernel(const ConvK p, int zseg, int zsegs) {
     constexpr bool X3 = MODE == WZ_F16X3;
     constexpr int CK = DDPM3D_CONV_CK, CINP = NCH * CK;
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_skinny_kernel(const ConvK p, in
 #pragma unroll
             for (int s = 0; s < NCH; ++s) {
                 {
-                    const f32x4 q0 = B16 ? bf16x4_expand(u32x2{cur[s][0][0], cur[s][0][1]}) : __builtin_bit_cast(f32x4, cur[s][0]);
-                    const f32x4 q1 = B16 ? bf16x4_expand(u32x2{cur[s][0][2], cur[s][0][3]}) : __builtin_bit_cast(f32x4, cur[s][1]);
+                    const f32x4 q0 = B16 ? half4_expand(u32x2{cur[s][0][0], cur[s][0][1]}, B16 == 2) : __builtin_bit_cast(f32x4, cur[s][0]);
+                    const f32x4 q1 = B16 ? half4_expand(u32x2{cur[s][0][2], cur[s][0][3]}, B16 == 2) : __builtin_bit_cast(f32x4, cur[s][1]);
                     const float* at = aff + 2 * (half * (CINP / 2) + s * 8);
                     float v[8];
 #pragma unroll
@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_skinny_kernel(const ConvK p, in
                 const float val = s_prev * oscale + bias;
                 const size_t vox = ((size_t)zo * p.H + y) * p.W + x;
                 if (p.out_layout == DDPM3D_OUT_NDHWC)
-                    ddpm3d_act_store(p.out, ((size_t)n * DHW + vox) * p.Cout + gco, val, (p.io & DDPM3D_IO_OUT_BF16) != 0);
+                    ddpm3d_act_store(p.out, ((size_t)n * DHW + vox) * p.Cout + gco, val, (p.io & DDPM3D_IO_OUT_BF16) != 0,
+                                     (p.io & DDPM3D_IO_HALF_IS_F16) != 0);
                 else
                     p.out[((size_t)n * p.Cout + gco) * DHW + vox] = val;
             }
@@ -242,7 +243,7 @@ static size_t skinny_lds_bytes(int CinPad) {
     return (size_t)(CinPad / DDPM3D_CONV_CK) * 2 * SK_COLS * 32 + (size_t)2 * CinPad * 4 + (size_t)128 * SK_PSTRIDE * 4;
 }
 
-template <int MODE, int NCH, bool B16>
+template <int MODE, int NCH, int B16>
 static hipError_t sk_launch(const ConvK& k, dim3 grid, int zseg, int zsegs, hipStream_t st) {
     const size_t lds = skinny_lds_bytes(NCH * DDPM3D_CONV_CK);
     if (lds > 65536) {
@@ -256,14 +257,16 @@ static hipError_t sk_launch(const ConvK& k, dim3 grid, int zseg, int zsegs, hipS
 }
 
 // Instantiated: Cin = 32, 64, 128 channels (base widths); fp32 sources in the f16x3 / f16 arithmetic, bf16
-// sources in the bf16 mode (whose residual stream is bf16).  Anything else stays on the general kernel
-// (api.hip asks here).
-bool ddpm3d_skinny_ok(int CinPad, int prec, bool src_bf16) {
+// sources in the bf16 mode and f16 sources in the f16 mode (the modes whose residual stream is 16-bit).
+// Anything else stays on the general kernel (api.hip asks here).  src16: 0 fp32, 1 bf16, 2 f16.
+bool ddpm3d_skinny_ok(int CinPad, int prec, int src16) {
     if (CinPad != 32 && CinPad != 64 && CinPad != 128) return false;
-    return prec == DDPM3D_PREC_BF16 ? src_bf16 : ((prec == DDPM3D_PREC_F16X3 || prec == DDPM3D_PREC_F16) && !src_bf16);
+    if (prec == DDPM3D_PREC_BF16) return src16 == 1;
+    if (prec == DDPM3D_PREC_F16) return src16 == 0 || src16 == 2;
+    return prec == DDPM3D_PREC_F16X3 && src16 == 0;
 }
 
-template <int MODE, bool B16>
+template <int MODE, int B16>
 static hipError_t sk_launch_mode(const ConvK& k, dim3 grid, int zseg, int zsegs, hipStream_t st) {
     if (k.CinPad == 32) return sk_launch<MODE, 2, B16>(k, grid, zseg, zsegs, st);
     if (k.CinPad == 64) return sk_launch<MODE, 4, B16>(k, grid, zseg, zsegs, st);
@@ -277,7 +280,10 @@ hipError_t ddpm3d_launch_conv_skinny(const ConvK& k, int prec, hipStream_t st) {
     while (zseg > 4 && (long long)tiles * ((k.D + zseg - 1) / zseg) < SK_MIN_WGS) zseg = (zseg + 1) / 2;
     const int zsegs = (k.D + zseg - 1) / zseg;
     const dim3 grid(tiles * zsegs);
-    if (prec == DDPM3D_PREC_F16) return sk_launch_mode<WZ_F16, false>(k, grid, zseg, zsegs, st);
-    if (prec == DDPM3D_PREC_BF16) return sk_launch_mode<WZ_BF16, true>(k, grid, zseg, zsegs, st);
-    return sk_launch_mode<WZ_F16X3, false>(k, grid, zseg, zsegs, st);
+    if (prec == DDPM3D_PREC_F16) {
+        if (k.io & DDPM3D_IO_SRC0_BF16) return sk_launch_mode<WZ_F16, 2>(k, grid, zseg, zsegs, st);   // f16 source
+        return sk_launch_mode<WZ_F16, 0>(k, grid, zseg, zsegs, st);
+    }
+    if (prec == DDPM3D_PREC_BF16) return sk_launch_mode<WZ_BF16, 1>(k, grid, zseg, zsegs, st);
+    return sk_launch_mode<WZ_F16X3, 0>(k, grid, zseg, zsegs, st);
 }

@@ -50,7 +50,8 @@ struct WzGeom {
 // Per-thread, launch-invariant part of the staging (256 staging threads, thread = lt).
 struct StageLane {
     unsigned vo0[WzGeom::NL], vo1[WzGeom::NL];   // byte offset of slot i's voxel at plane zb in src0 / src1
-    unsigned es0, es1;                           // bytes per element of src0 / src1 (4, or 2 = bf16)
+    unsigned es0, es1;                           // bytes per element of src0 / src1 (4, or 2 = bf16 / f16)
+    bool f16;                                    // the 2-byte elements are IEEE f16, not bf16
     int lds[WzGeom::NL];                         // byte offset of slot i inside a plane of the image
     bool ok[WzGeom::NL];                         // slot exists and its (y, x) lies inside the volume
     unsigned plane0, plane1;                     // bytes per z-plane of src0 / src1
@@ -70,6 +71,7 @@ __device__ __forceinline__ StageLane stage_lane(const ConvK& p, int lt, int n, i
     s.zb = zb;
     s.es0 = (p.io & DDPM3D_IO_SRC0_BF16) ? 2u : 4u;
     s.es1 = (p.io & DDPM3D_IO_SRC1_BF16) ? 2u : 4u;
+    s.f16 = (p.io & DDPM3D_IO_HALF_IS_F16) != 0;
     s.plane0 = (unsigned)(Hs * Ws) * (unsigned)p.C0 * s.es0;
     s.plane1 = (unsigned)(Hs * Ws) * (unsigned)p.C1 * s.es1;
     // act: e = exp2(-y log2e) with yS = S y;  none: e = exp2(-126) ~ 1e-38, 1 + e == 1, yS * 1 = yS
@@ -164,7 +166,7 @@ __device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             if (r.zmask & (1u << k)) {
-                const f32x4 x = quad_bits_expand(r.v[i][k], r.b16);
+                const f32x4 x = quad_bits_expand(r.v[i][k], r.b16, s.f16);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float ys = __builtin_fmaf(x[c], sa[c], sb[c]);

@@ -27,6 +27,7 @@ PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16, "bf16": PRE
 WINOGRAD_OF = {PREC_F16X3: PREC_F16X3_WZ, PREC_F16: PREC_F16_WZ, PREC_BF16: PREC_BF16_WZ}
 # ddpm3d_conv_desc.io_dtype bits: which activation tensors hold bf16
 IO_SRC0_BF16, IO_SRC1_BF16, IO_OUT_BF16, IO_RES_BF16 = 1, 2, 4, 8
+IO_HALF_IS_F16 = 16    # the flagged tensors hold IEEE f16 (the --use_fp16 storage), not bf16
 ABI_VERSION = 10
 # ddpm3d_conv_desc.kernel_hint bits (launch orders of identical arithmetic; tests and A/B measurements)
 HINT_WSTAT_OFF, HINT_WSTAT_ON = 0x100, 0x200

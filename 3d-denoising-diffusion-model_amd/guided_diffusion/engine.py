@@ -36,8 +36,9 @@ class Act:
         self.buf, self.C, self.D, self.H, self.W, self.stats, self.rows = buf, Cn, D, Hh, W, stats, rows
 
     @property
-    def bf16(self):
-        return self.buf.dtype == torch.bfloat16
+    def half(self):
+        """stored in 16 bits (bf16 in the bf16 mode, IEEE f16 in the f16 mode)"""
+        return self.buf.dtype in (torch.bfloat16, torch.float16)
 
     @property
     def voxels(self):
@@ -257,9 +258,10 @@ class _Plan:
         self.pool = {}
         self.act_bytes = 0
 
-        # bf16 mode: the residual stream (every tensor a conv writes and convs read) is stored in
-        # bf16; tensors read by the fp32-only kernels (attention, subsample, gn_stats) stay fp32
-        self.bf16 = eng.precision == "bf16"
+        # bf16 / f16 modes: the residual stream (every tensor a conv writes and convs read) is stored in
+        # 16 bits -- bf16, or IEEE f16 as the reference's --use_fp16 torso does (unet.py:1035,
+        # fp16_util.py:15-22); tensors read by the fp32-only kernels (attention, subsample, gn_stats) stay fp32
+        self.half_dtype = {"bf16": torch.bfloat16, "f16": torch.float16}.get(eng.precision)
         # only the split-f16 arithmetic scales its operands from in_bound (api.hip: prec_scaled); the exact
         # and the bf16 plans enqueue neither the input-range pass nor bound-only finalizes
         self.scaled = eng.precision in ("f16x3", "f16")
@@ -268,7 +270,7 @@ class _Plan:
             # the statistics buffer is attached by the conv step that produces the tensor
             # (its row count depends on how that conv is tiled / split)
             numel = N * d * h * w * Cn
-            dt = torch.bfloat16 if (self.bf16 and not fp32) else torch.float32
+            dt = self.half_dtype if (self.half_dtype is not None and not fp32) else torch.float32
             free = self.pool.get((numel, dt))
             if free:
                 buf = free.pop()
@@ -419,10 +421,12 @@ class _Plan:
         d.act = act
         io = 0
         if not planar:
-            io |= H.IO_SRC0_BF16 if srcs[0].bf16 else 0
-            io |= H.IO_SRC1_BF16 if (len(srcs) > 1 and srcs[1].bf16) else 0
-        io |= H.IO_OUT_BF16 if (out is not None and out.bf16) else 0
-        io |= H.IO_RES_BF16 if (res is not None and res.bf16) else 0
+            io |= H.IO_SRC0_BF16 if srcs[0].half else 0
+            io |= H.IO_SRC1_BF16 if (len(srcs) > 1 and srcs[1].half) else 0
+        io |= H.IO_OUT_BF16 if (out is not None and out.half) else 0
+        io |= H.IO_RES_BF16 if (res is not None and res.half) else 0
+        if io and self.half_dtype == torch.float16:
+            io |= H.IO_HALF_IS_F16
         d.io_dtype = io
         if self.scaled:
             if bound is None or bound[0] is None:
@@ -457,8 +461,10 @@ class _Plan:
         # (api.hip's rule for the one-or-two-cout kernel, conv3d_skinny.hip)
         if (pc.k == 3 and pc.Cout <= 2 and d.in_mode == H.IN_SAME and d.C1 == 0 and not d.stats
                 and res_mode == H.RES_NONE and d.Cin in (32, 64, 128)
-                and ((pc_use.precision == H.PREC_BF16) == bool(d.io_dtype & H.IO_SRC0_BF16))
-                and pc_use.precision in (H.PREC_F16X3, H.PREC_F16, H.PREC_BF16)):
+                and ((pc_use.precision == H.PREC_BF16 and (d.io_dtype & H.IO_SRC0_BF16))
+                     or (pc_use.precision == H.PREC_F16
+                         and (not (d.io_dtype & H.IO_SRC0_BF16) or (d.io_dtype & H.IO_HALF_IS_F16)))
+                     or (pc_use.precision == H.PREC_F16X3 and not (d.io_dtype & H.IO_SRC0_BF16)))):
             tag = "conv3d_p%d_k3_skinny" % pc_use.precision
         self.conv_meta[len(self.steps)] = (tag, flops)
         self.steps.append((self.eng.lib.ddpm3d_conv3d, [C.byref(d), 0]))

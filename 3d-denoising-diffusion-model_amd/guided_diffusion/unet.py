@@ -237,10 +237,12 @@ class UNetModel_noatt(nn.Module):
     # ---- precision switches (unet.py:999-1013) -------------------------------
     def convert_to_fp16(self):
         """The reference halves the conv weights of the torso and feeds fp16 activations
-        (fp32 GroupNorm, fp32 time-embed / emb_layers / final conv).  Here: every conv's
-        operands are rounded to f16 on their way into the matrix cores (one f16 MFMA per
-        product), accumulation, storage, GroupNorm and the timestep path stay fp32.
-        Parameters keep their fp32 storage (`state_dict` is unchanged)."""
+        (fp32 GroupNorm, fp32 time-embed / emb_layers / final conv; unet.py:999-1005, :1035).
+        Here: every conv's operands are rounded to f16 on their way into the matrix cores
+        (one f16 MFMA per product) and the residual stream -- every tensor the torso's convs
+        write and read -- is STORED in f16 (ddpm3d_conv_desc.io_dtype, DDPM3D_IO_HALF_IS_F16);
+        accumulation, GroupNorm statistics, the timestep path, the network's input and its
+        output stay fp32.  Parameters keep their fp32 storage (`state_dict` is unchanged)."""
         self.dtype = torch.float16
         self.conv_precision = "f16"
 

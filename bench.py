@@ -89,9 +89,10 @@ ARITH = {
               "fp32 data/accumulators; each product of the convs = 3 f16 MFMAs on hi/lo-split "
               "operands (error below fp32 accumulation error)",
               "f16 MFMA dense (2500) / 3 MFMAs per algorithmic fp32 product"),
-    "f16": ("f16 operands, f32 accumulate/storage",
-            "conv operands rounded to f16 (one MFMA per product), fp32 accumulation, storage, "
-            "GroupNorm and timestep path: the reference's --use_fp16 analogue", "f16 MFMA dense"),
+    "f16": ("f16",
+            "conv operands rounded to f16 (one MFMA per product) and the residual stream stored in f16, as the "
+            "reference's --use_fp16 torso (unet.py:1035); fp32 accumulation, GroupNorm statistics, timestep "
+            "path, network input and output", "f16 MFMA dense"),
     "bf16": ("bf16",
              "conv operands rounded to bf16 (one bf16 MFMA per product) and the residual stream stored in "
              "bf16; fp32 accumulation, GroupNorm statistics, timestep path, network input and output",

@@ -138,8 +138,9 @@ typedef struct ddpm3d_conv_desc {
     int32_t in_bound_count;
     const float* in_bound;
     int32_t in_bound_stride;
-    /* DDPM3D_IO_* bits: which of the activation tensors hold bf16 instead of fp32 elements (same
-     * NDHWC layout, 2 bytes per element, 8-byte aligned).  Statistics, affine tables, bias and
+    /* DDPM3D_IO_* bits: which of the activation tensors hold 16-bit (bf16, or f16 with
+     * DDPM3D_IO_HALF_IS_F16) instead of fp32 elements (same NDHWC layout, 2 bytes per element, 8-byte
+     * aligned).  Statistics, affine tables, bias and
      * the NCDHW output are fp32 always.  This is the bf16 mode's placement of the reference's
      * fp16 torso (unet.py:999-1005, :1035, :1043): the residual stream in 16 bits, GroupNorm and the
      * edges of the network in fp32. */
@@ -150,7 +151,11 @@ enum {
     DDPM3D_IO_SRC0_BF16 = 1,
     DDPM3D_IO_SRC1_BF16 = 2,
     DDPM3D_IO_OUT_BF16 = 4,    /* with DDPM3D_OUT_NDHWC only */
-    DDPM3D_IO_RES_BF16 = 8
+    DDPM3D_IO_RES_BF16 = 8,
+    /* the tensors flagged above hold IEEE f16 instead of bf16 (all of them): the reference's own
+     * --use_fp16 storage of the torso (unet.py:1035 `h = x.type(self.dtype)`, fp16_util.py:15-22).
+     * Values beyond 65504 become inf, as they do there. */
+    DDPM3D_IO_HALF_IS_F16 = 16
 };
 
 /* ddpm3d_conv_desc.kernel_hint */

@@ -28,7 +28,7 @@ def pack(w, precision=0):
 
 def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res=None, res_mode=H.RES_NONE,
            out_layout=H.OUT_NDHWC, want_stats=True, planar=False, bias_stride_n=0, precision=0, hint=0,
-           bound=None, out_bf16=False):
+           bound=None, out_bf16=False, out_f16=False):
     """srcs: list of NDHWC device tensors (or two (N,1,D,H,W) volumes when planar).
     bound: [N, k] device tensor of upper bounds of the input as the matrix cores see it
     (ddpm3d_conv_desc.in_bound); default = the exact maximum of |act(A*x + B)| per sample.
@@ -49,9 +49,13 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
         if len(srcs) > 1:
             d.src1, d.C1 = H.ptr(srcs[1]), srcs[1].shape[-1]
         d.Cin = d.C0 + d.C1
-        # bf16 tensors are recognised by their dtype (ddpm3d_conv_desc.io_dtype)
-        d.io_dtype |= H.IO_SRC0_BF16 if srcs[0].dtype == torch.bfloat16 else 0
-        d.io_dtype |= H.IO_SRC1_BF16 if (len(srcs) > 1 and srcs[1].dtype == torch.bfloat16) else 0
+        # 16-bit tensors are recognised by their dtype (ddpm3d_conv_desc.io_dtype); f16 ones set the
+        # descriptor-wide IO_HALF_IS_F16 (a call mixes fp32 with ONE 16-bit type)
+        half = (torch.bfloat16, torch.float16)
+        d.io_dtype |= H.IO_SRC0_BF16 if srcs[0].dtype in half else 0
+        d.io_dtype |= H.IO_SRC1_BF16 if (len(srcs) > 1 and srcs[1].dtype in half) else 0
+        if any(s_.dtype == torch.float16 for s_ in srcs):
+            d.io_dtype |= H.IO_HALF_IS_F16
     assert d.Cin == ci
     if aff is not None:
         d.aff_a, d.aff_b = H.ptr(aff[0]), H.ptr(aff[1])
@@ -74,13 +78,13 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
     wp = pack(w, precision)
     d.w_packed, d.bias, d.bias_stride_n = H.ptr(wp), H.ptr(b), bias_stride_n
     d.res_mode, d.res = res_mode, H.ptr(res)
-    if res is not None and res.dtype == torch.bfloat16:
-        d.io_dtype |= H.IO_RES_BF16
-    if out_bf16:
-        d.io_dtype |= H.IO_OUT_BF16
+    if res is not None and res.dtype in (torch.bfloat16, torch.float16):
+        d.io_dtype |= H.IO_RES_BF16 | (H.IO_HALF_IS_F16 if res.dtype == torch.float16 else 0)
+    if out_bf16 or out_f16:
+        d.io_dtype |= H.IO_OUT_BF16 | (H.IO_HALF_IS_F16 if out_f16 else 0)
     if out_layout == H.OUT_NDHWC:
-        out = torch.full((N, D, Hh, W, co), float("nan"), dtype=torch.bfloat16 if out_bf16 else torch.float32,
-                         device=dev)
+        odt = torch.bfloat16 if out_bf16 else (torch.float16 if out_f16 else torch.float32)
+        out = torch.full((N, D, Hh, W, co), float("nan"), dtype=odt, device=dev)
     else:
         out = torch.full((N, co, D, Hh, W), float("nan"), dtype=torch.float32, device=dev)
     d.out, d.out_layout = H.ptr(out), out_layout

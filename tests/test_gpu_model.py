@@ -171,6 +171,10 @@ def test_convert_to_fp16_ddim_psnr(golden):
     mse = float(((out.cpu().numpy() - ref) ** 2).mean())
     psnr = 10 * np.log10(4.0 / mse)            # data range [-1, 1]
     assert psnr > 35.0, psnr
+    # the torso's tensors are STORED in f16 too, as the reference's --use_fp16 does (unet.py:1035)
+    plan = model.engine().plan(*[shape[0]] + list(shape[2:]))
+    assert plan.half_dtype == torch.float16 and any(b.dtype == torch.float16 for b in plan.keep
+                                                    if isinstance(b, torch.Tensor))
     assert set(model.state_dict()) == set(build(TINY)[0].state_dict())   # parameters stay fp32 / same keys
     assert all(v.dtype == torch.float32 for v in model.state_dict().values())
 
@@ -196,7 +200,7 @@ def test_bf16_mode_ddim_psnr(golden):
     assert all(v.dtype == torch.float32 for v in model.state_dict().values())
     # the plan really stores the residual stream in bf16
     plan = next(iter(model.engine().plans.values()))
-    assert plan.bf16 and any(b.dtype == torch.bfloat16 for b in plan.keep if isinstance(b, torch.Tensor))
+    assert plan.half_dtype == torch.bfloat16 and any(b.dtype == torch.bfloat16 for b in plan.keep if isinstance(b, torch.Tensor))
 
 
 def test_p_sample_loop_api_and_determinism():
