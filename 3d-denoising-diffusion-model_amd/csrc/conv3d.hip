@@ -307,7 +307,8 @@ __global__ __launch_bounds__(256, (PIPEM == 2 ? 1 : (TXL == 2 ? 2 : 3))) void co
     if (!wave_active) return;
 
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<PREC, WM, MT, TXL, TYL>(p, acc, n, z0, y0, x0, tile_in_n, wm, cout, half, wg.split, asc.inv);
+    conv_epilogue<PREC, WM, MT, TXL, TYL, PREC == 2 || PREC == 5>(p, acc, n, z0, y0, x0, tile_in_n, wm, cout, half, wg.split,
+                                                                 asc.inv);
 }
 
 // This file is compiled once per arithmetic mode (-DDDPM3D_PREC_ONLY=0|1|2|5, and 3 = the
@@ -332,7 +333,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) 
     const size_t slab_stride = (size_t)p.N * DHW * p.Cout;
     for (int cout = threadIdx.x; cout < p.Cout; cout += 256) {
         const float bias = p.bias[(size_t)n * p.bias_stride_n + cout];
-        double s1 = 0.0, s2 = 0.0;
+        GnAcc gs;
+        gs.init(0.0f);
+        float cnt = 0.0f;
         for (size_t v = v0; v < v1; ++v) {
             const size_t e = ((size_t)n * DHW + v) * p.Cout + cout;
             float val = p.partial[e];
@@ -346,10 +349,13 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvK p) 
                 ddpm3d_act_store(p.out, e, val, (p.io & DDPM3D_IO_OUT_BF16) != 0, (p.io & DDPM3D_IO_HALF_IS_F16) != 0);
             else
                 p.out[((size_t)n * p.Cout + cout) * DHW + v] = val;
-            gn_sums_add(s1, s2, val);
+            if (cnt == 0.0f) gs.init(val);
+            gs.add(val);
+            cnt += 1.0f;
         }
         if (p.stats != nullptr)
-            *reinterpret_cast<double2*>(p.stats + (((size_t)n * p.Cout + cout) * rows + r) * 2) = make_double2(s1, s2);
+            *reinterpret_cast<double2*>(p.stats + (((size_t)n * p.Cout + cout) * rows + r) * 2) =
+                make_double2(gs.sum1(cnt), gs.sum2(cnt));
     }
 }
 
@@ -372,7 +378,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK 
     {
         const int q = blockIdx.y * 64 + cq;
         const bool qok = q < quads;
-        double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+        GnAcc gs[4];
+        float cnt = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gs[c].init(0.0f);
         if (qok) {
             const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + (size_t)n * p.bias_stride_n + q * 4);
 #pragma unroll
@@ -405,15 +414,19 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK 
                     else
                         *reinterpret_cast<f32x4*>(p.out + e) = val;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) gn_sums_add(s1[c], s2[c], val[c]);
+                    for (int c = 0; c < 4; ++c) {
+                        if (cnt == 0.0f) gs[c].init(val[c]);
+                        gs[c].add(val[c]);
+                    }
+                    cnt += 1.0f;
                 }
             }
         }
         if (p.stats != nullptr) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                red[0][vl][cq * 4 + c] = s1[c];
-                red[1][vl][cq * 4 + c] = s2[c];
+                red[0][vl][cq * 4 + c] = gs[c].sum1(cnt);
+                red[1][vl][cq * 4 + c] = gs[c].sum2(cnt);
             }
             __syncthreads();
             if (vl == 0 && qok) {

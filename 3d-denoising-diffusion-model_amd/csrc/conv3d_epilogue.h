@@ -58,7 +58,8 @@ __device__ __forceinline__ void quad_transpose(float (&a)[4], bool b0, bool b1) 
 // the raw split-K slab.  C/D map of a 32x32 MFMA: col = lane&31 (cout),
 // row = (reg&3) + 8*(reg>>2) + 4*half.
 // inv_act = 1 / activation scale of this sample (split-f16 modes; 1 in the exact mode)
-template <int PREC, int WM, int MT, int TXL, int TYL>
+// WIDE: the 16-byte store form below (one-MFMA modes), or the four-byte form
+template <int PREC, int WM, int MT, int TXL, int TYL, bool WIDE = false>
 // pre_ws / pre_bias (pre = true): p.wscale[cout] and the lane's bias, loaded by the caller at kernel
 // START (conv3d_wz.h): at the epilogue's start they are a dependent global load -- ~2k cycles at the
 // head of a phase in which the wave issues no MFMA
@@ -126,7 +127,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 if (r16) return ddpm3d_half_to_float((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rrsrc, roff_, so, 0), f16);
                 return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrsrc, roff_, so, 0));
             };
-            // ---- WIDE form (r03): residual none / same and Cout % 4 == 0 -- every such launch of the network.
+            // ---- WIDE form (r03): residual none / same and Cout % 4 == 0, in the ONE-MFMA modes (f16, bf16).
+            // Same box, whole forward (profiles/r03_lib_ab_epilogue_forms_{f16x3,bf16,f16,f32}.txt): -3...4 % there; +0.4 % in the
+            // f16x3 mode and +1.4 % in the exact mode, whose epilogues hide behind three and sixteen times the
+            // MFMA work and only pay for the transposes -- those keep the four-byte form.
             // Phase stamps of the dominant kernel (profiles/r03_wz_stamps_*.txt) put its epilogue at 8 % of a
             // wave's life without a residual and 11.5 % with one: 64 four-byte stores (+ 64 four-byte loads) per
             // lane, bound by the CU's store ISSUE rate (~7 B/clk/CU), not by bandwidth.  A lane's registers
@@ -134,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
             // four consecutive couts of ONE voxel: 16 stores of 16 bytes (one wave instruction = 8 voxels x
             // 128 contiguous bytes), the residual read the same way.  The statistics are taken in the
             // transposed layout (after the residual add) and folded over the quad and the two halves.
-            if ((rm == DDPM3D_RES_NONE || rm == DDPM3D_RES_SAME) && (p.Cout & 3) == 0) {
+            if (WIDE && (rm == DDPM3D_RES_NONE || rm == DDPM3D_RES_SAME) && (p.Cout & 3) == 0) {
                 const int li = threadIdx.x & 3;
                 const bool b0 = (li & 1) != 0, b1 = (li & 2) != 0;
                 const unsigned lane_vox = (((unsigned)z0 * p.H + y0 + hy) * p.W + x0 + hx + li);
@@ -142,7 +146,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 const unsigned wv = cvalid ? lane_vox * cstride + cq * eso : DDPM3D_OOB_OFFSET;
                 const unsigned wr = cvalid ? lane_vox * rstride + cq * esr : DDPM3D_OOB_OFFSET;
                 const float bias_w = (!split && cvalid) ? (pre ? pre_bias : p.bias[(size_t)n * p.bias_stride_n + cout]) : 0.0f;
-                double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};
+                GnAcc ga[4];
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     f32x4 rq[4];
@@ -169,7 +173,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 if (resid) a[i] += rq[g][i];
-                                if (p.stats != nullptr) gn_sums_add(d1[i], d2[i], a[i]);
+                                if (p.stats != nullptr) {
+                                    if (t == 0 && g == 0) ga[i].init(a[i]);
+                                    ga[i].add(a[i]);
+                                }
                             }
                         }
                         const int m0 = (wm * MT + t) * 32 + 8 * g;
@@ -185,8 +192,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 }
                 if (!split && p.stats != nullptr) {
                     // fold the quad's four voxel lanes and the two halves; then lane li keeps cout cq + li = its own
+                    double d1[4], d2[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+                        d1[i] = ga[i].sum1((float)(MT * 4));
+                        d2[i] = ga[i].sum2((float)(MT * 4));
                         d1[i] += __shfl_xor(d1[i], 1); d2[i] += __shfl_xor(d2[i], 1);
                         d1[i] += __shfl_xor(d1[i], 2); d2[i] += __shfl_xor(d2[i], 2);
                         d1[i] += __shfl_xor(d1[i], 32); d2[i] += __shfl_xor(d2[i], 32);
@@ -203,7 +213,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
             }
             roff_ = cvalid ? rbase : DDPM3D_OOB_OFFSET;
             const float bias = (!split && cvalid) ? (pre ? pre_bias : p.bias[(size_t)n * p.bias_stride_n + cout]) : 0.0f;
-            double s1 = 0.0, s2 = 0.0;   // GroupNorm partial sums in fp64 (gn_sums_add below)
+            GnAcc gs;   // GroupNorm partial sums (conv3d_params.h)
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 unsigned soff[16];
@@ -246,7 +256,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                     if (!split) {
                         val += bias;
                         if (resid) val += r[reg];
-                        gn_sums_add(s1, s2, val);
+                        if (t == 0 && reg == 0) gs.init(val);
+                        gs.add(val);
                     }
                     if (o16)
                         __builtin_amdgcn_raw_buffer_store_b16(ddpm3d_to_half(val, f16), drsrc, voff, soff[reg], 0);
@@ -255,6 +266,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                 }
             }
             if (!split && p.stats != nullptr) {
+                double s1 = gs.sum1((float)(MT * 16)), s2 = gs.sum2((float)(MT * 16));
                 s1 += __shfl_xor(s1, 32);
                 s2 += __shfl_xor(s2, 32);
                 if (half == 0 && cvalid) {
@@ -286,7 +298,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
         return;
     }
     const float bias = cvalid ? (pre ? pre_bias : p.bias[(size_t)n * p.bias_stride_n + cout]) : 0.0f;
-    double s1 = 0.0, s2 = 0.0;
+    GnAcc gs;
+    gs.init(0.0f);
+    float cnt = 0.0f;
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -305,11 +319,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                                      (p.io & DDPM3D_IO_HALF_IS_F16) != 0);
                 else
                     p.out[((size_t)n * p.Cout + cout) * DHW + vox] = val;
-                gn_sums_add(s1, s2, val);
+                if (cnt == 0.0f) gs.init(val);      // pivot = the lane's first valid value
+                gs.add(val);
+                cnt += 1.0f;
             }
         }
     }
     if (p.stats != nullptr) {
+        double s1 = gs.sum1(cnt), s2 = gs.sum2(cnt);
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (half == 0 && cvalid) {

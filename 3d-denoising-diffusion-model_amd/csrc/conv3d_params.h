@@ -158,16 +158,33 @@ hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st);
 hipError_t ddpm3d_launch_conv_skinny(const ConvK& k, int prec, hipStream_t st);   // conv3d_skinny.hip
 bool ddpm3d_skinny_ok(int CinPad, int prec, int src16);   // src16: 0 fp32, 1 bf16, 2 f16
 
-// GroupNorm partial sums are accumulated and stored in fp64 (r03).  With fp32 sums the variance
-// E[x^2] - mean^2 loses |mean|^2 / var x 1e-7 of its value to cancellation -- invisible on
-// normalised data, 1e-2 on a tensor whose mean is 300 standard deviations (un-normalised PET counts
-// behind the first conv, scripts/test.py:201-203).  fp64 add / fma issue at the fp32 rate on gfx950;
-// per stored element this is one conversion more than the fp32 form.
-__device__ __forceinline__ void gn_sums_add(double& s1, double& s2, float val) {
-    const double v = (double)val;
-    s1 += v;
-    s2 = __builtin_fma(v, v, s2);
-}
+// GroupNorm partial sums are STORED in fp64 (r03).  With fp32 sums the variance E[x^2] - mean^2 loses
+// |mean|^2 / var x 1e-7 of its value to cancellation -- invisible on normalised data, 1e-2 on a tensor
+// whose mean is 300 standard deviations (un-normalised PET counts behind the first conv,
+// scripts/test.py:201-203).  A lane ACCUMULATES in fp32 around a pivot -- the first value it sees --
+//     s1 = sum (x - p),  s2 = sum (x - p)^2          (no cancellation: x - p is of the size of the spread)
+// and converts once, in fp64:  sum x = n p + s1,  sum x^2 = s2 + 2 p s1 + n p^2.  Three fp32 instructions
+// per element (fp64 accumulation per element cost the HBM-bound 1x1 and pooled-input kernels 2-10 %:
+// profiles/r03_tree_ab_r02_vs_r03_*.txt).  -DDDPM3D_STATS_F64: per-element fp64 accumulation (measurement).
+struct GnAcc {
+#ifdef DDPM3D_STATS_F64
+    double a1, a2;
+    __device__ __forceinline__ void init(float) { a1 = 0.0; a2 = 0.0; }
+    __device__ __forceinline__ void add(float v) { const double d = (double)v; a1 += d; a2 = __builtin_fma(d, d, a2); }
+    __device__ __forceinline__ double sum1(float) const { return a1; }
+    __device__ __forceinline__ double sum2(float) const { return a2; }
+#else
+    float p, s1, s2;
+    __device__ __forceinline__ void init(float pivot) { p = pivot; s1 = 0.0f; s2 = 0.0f; }
+    __device__ __forceinline__ void add(float v) { const float d = v - p; s1 += d; s2 = __builtin_fmaf(d, d, s2); }
+    // n = number of values added
+    __device__ __forceinline__ double sum1(float n) const { return (double)n * (double)p + (double)s1; }
+    __device__ __forceinline__ double sum2(float n) const {
+        const double dp = (double)p;
+        return (double)s2 + 2.0 * dp * (double)s1 + (double)n * dp * dp;
+    }
+#endif
+};
 
 // Residual term of the conv epilogue for output element (n, z, y, x, cout);
 // shared by the conv kernel and the split-K reduce kernel.
