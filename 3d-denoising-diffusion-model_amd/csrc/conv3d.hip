@@ -510,17 +510,16 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     else if (c.PREC == DDPM3D_PREC_BF16_WZ)
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_BF16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     else {
-        // kernel_hint bits 12..14: force an issue order (A/B measurements; identical arithmetic), 0 = by shape
+        // kernel_hint bits 12..14: force an issue order (A/B measurements; identical arithmetic), 0 = the default.
+        // Built: 0, 1 (r02's two), 2, 4 (r03); 3, 5, 6 of conv3d_wz.h were measured and are not instantiated
+        // (every instantiation is ~1 MB of code object to load at the first launch)
         int order = (k.hint & DDPM3D_HINT_WZ_ORDER_MASK) >> DDPM3D_HINT_WZ_ORDER_SHIFT;
         if (order == 0) order = 5;   // (value = IL + 1): weight loads first, reads behind, wave priority 1
         switch (order - 1) {
             case 0: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 0>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
             case 1: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 1>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
             case 2: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 2>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
-            case 3: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 3>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
             case 4: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
-            case 5: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 5>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
-            case 6: hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 6>), dim3(gx, gy, k.ksplit), dim3(256), lds, st, k); break;
             default: return hipErrorInvalidValue;
         }
     }
