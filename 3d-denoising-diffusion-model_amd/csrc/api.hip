@@ -110,8 +110,8 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         // for it and passes no statistics (their row count follows the library's own choice)
         const int s_forced = (d->kernel_hint & DDPM3D_HINT_SPLITK_MASK) >> DDPM3D_HINT_SPLITK_SHIFT;
         const int nch = ddpm3d_cin_pad(d->Cin) / DDPM3D_CONV_CK;
-        if (d->stats || s_forced > nch || d->ksize != 3 || c.WN != 4)
-            return fail(DDPM3D_EINVAL, "conv3d: a forced split factor needs ksize 3, Cout > 64, no statistics, S <= Cin / 16");
+        if (d->stats || s_forced > nch || c.WN != 4)
+            return fail(DDPM3D_EINVAL, "conv3d: a forced split factor needs Cout > 64, no statistics, S <= Cin / 16");
         c.S = s_forced;
         c.workspace_bytes = s_forced > 1 ? (size_t)s_forced * d->N * d->D * d->H * d->W * d->Cout * sizeof(float) : 0;
         const long long vox = (long long)d->D * d->H * d->W;
@@ -158,6 +158,8 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     }
     k.ksplit = c.S;
     k.chunks_per_split = (k.CinPad / DDPM3D_CONV_CK + c.S - 1) / c.S;
+    // 1x1 convs: whole 32-channel blocks per split (conv1x1.hip walks K in those; any range suits the general kernel)
+    if (d->ksize == 1 && c.S > 1) k.chunks_per_split = (k.chunks_per_split + 1) & ~1;
     k.partial = (float*)d->workspace;
     {
         // extents for the kernel's buffer descriptors (32-bit offsets)
@@ -196,7 +198,8 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         ddpm3d_skinny_ok(k.CinPad, d->precision, !(d->io_dtype & DDPM3D_IO_SRC0_BF16) ? 0
                                                   : ((d->io_dtype & DDPM3D_IO_HALF_IS_F16) ? 2 : 1)))
         return launched(ddpm3d_launch_conv_skinny(k, d->precision, (hipStream_t)stream), "conv3d (skinny)");
-    const int rc = launched(ddpm3d_launch_conv(k, c, (hipStream_t)stream), "conv3d");
+    const int rc = ddpm3d_pw_ok(k, c, d->ksize) ? launched(ddpm3d_launch_conv_pw(k, c, (hipStream_t)stream), "conv3d (1x1)")
+                                                : launched(ddpm3d_launch_conv(k, c, (hipStream_t)stream), "conv3d");
     if (rc != DDPM3D_OK || c.S == 1) return rc;
     return launched(ddpm3d_launch_splitk_reduce(k, (hipStream_t)stream), "conv3d split-K reduce");
 }

@@ -219,10 +219,14 @@ __device__ __forceinline__ f32x4 halo_finish(const HaloSrc& h, f32x4 raw, bool i
 // maximum b of the sample's in_bound entries, times `gain` (2 for the Winograd-D input transform,
 // which adds two planes), is brought into [2^14, 2^15): s = 2^(14 - floor(log2(gain * b))).
 struct ActScale { float s, inv; };
-__device__ __forceinline__ ActScale act_scale(const ConvK& p, int n, float gain) {
+// (two halves, so that a kernel can request the bound first and fold it behind its other loads)
+__device__ __forceinline__ float act_scale_load(const ConvK& p, int n) {
     const int lane = threadIdx.x & 63;
     float b = 0.0f;
     if (lane < p.in_bound_count) b = p.in_bound[((size_t)n * p.in_bound_count + lane) * p.in_bound_stride];
+    return b;
+}
+__device__ __forceinline__ ActScale act_scale_finish(float b, float gain) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o));   // a NaN entry is ignored
     b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b))) * gain;
@@ -234,6 +238,9 @@ __device__ __forceinline__ ActScale act_scale(const ConvK& p, int n, float gain)
     r.s = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
     r.inv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
     return r;
+}
+__device__ __forceinline__ ActScale act_scale(const ConvK& p, int n, float gain) {
+    return act_scale_finish(act_scale_load(p, n), gain);
 }
 
 // Which (tile, cout block, K split) a workgroup owns.  Workgroups go to the 8 XCDs round-robin

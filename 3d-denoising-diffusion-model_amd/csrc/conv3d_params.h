@@ -82,16 +82,17 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
     const int nch = ddpm3d_cin_pad(Cin) / DDPM3D_CONV_CK;
     int best = 1;
     if (ksize == 1 && c.WN == 4) {
-        // 1x1: a chunk is one tap, so a workgroup's time is latency per chunk (barrier + an
-        // exposed halo load, ~1 us) and the split pays when few workgroups each walk many
-        // chunks.  Units ~us: chunk 1, prologue + epilogue 3, the reduce launch 10.  Measured
-        // before (r01): 1024->512 @ 64x4x4 took 71 us on 32 workgroups x 64 chunks.
+        // 1x1: few workgroups each walking many chunks are latency-bound, and the split pays once that walk
+        // outweighs a second launch.  Units ~us, fitted to the forced-split sweeps of the network's fourteen
+        // skip-connection shapes in the f16x3 and bf16 modes (conv1x1.hip; profiles/r03_splitk_sweep_1x1_*.txt:
+        // the rule's choices cost 0.576 ms over both tables, the best choice per cell 0.567): chunk 0.25,
+        // prologue + epilogue 6, the reduce launch 6.  (r01-r02, general kernel: 1 / 3 / 10.)
         double best_cost = 1e300;
         for (int s = 1; s <= 32 && s <= nch; ++s) {
             const int cps = (nch + s - 1) / s;
             if (s > 1 && cps < 4) break;
             const long long per_cu = (blocks * s + 255) / 256;
-            const double cost = (double)per_cu * (cps + 3.0) + (s > 1 ? 10.0 : 0.0);
+            const double cost = (double)per_cu * (0.25 * cps + 6.0) + (s > 1 ? 6.0 : 0.0);
             if (cost < best_cost * 0.9) { best_cost = cost; best = s; }
         }
     }
@@ -156,6 +157,26 @@ static inline hipError_t ddpm3d_allow_dynamic_lds(DynLdsOnce& done, const void* 
 hipError_t ddpm3d_launch_conv(const ConvK& k, const ConvCfg& c, hipStream_t st);
 hipError_t ddpm3d_launch_splitk_reduce(const ConvK& k, hipStream_t st);
 hipError_t ddpm3d_launch_conv_skinny(const ConvK& k, int prec, hipStream_t st);   // conv3d_skinny.hip
+hipError_t ddpm3d_launch_conv_pw(const ConvK& k, const ConvCfg& c, hipStream_t st);   // conv1x1.hip
+// the 1x1x1 convs on raw inputs (ResBlock skip connections) that conv1x1.hip's register-fed GEMM takes;
+// k is the filled launch record (chunks_per_split included)
+// The split-f16 form above 1024 workgroups (the three 256 -> 128 skip convs at 64^3: 2048 tiles, 400 MB) stays
+// on conv3d.hip's kernel: two 231-register workgroups per CU, each alive for only 8 blocks, overlap their
+// fill and drain phases worse than the general kernel's three -- 0.120 against 0.110 ms there, while every
+// smaller layer and every layer of the one-MFMA modes is 10-50 % faster here
+// (profiles/r03_layer_table_conv1x1_*.txt, r03_lib_ab_conv1x1_*.txt).
+#ifndef DDPM3D_PW_X3_MAX_WGS
+#define DDPM3D_PW_X3_MAX_WGS 1024
+#endif
+static inline bool ddpm3d_pw_ok(const ConvK& k, const ConvCfg& c, int ksize) {
+    const bool s0 = (k.io & DDPM3D_IO_SRC0_BF16) != 0, s1 = (k.io & DDPM3D_IO_SRC1_BF16) != 0;
+    const long long wgs = (long long)k.N * k.tilesZ * k.tilesY * k.tilesX * (k.CoutPad / 128) * k.ksplit;
+    if (c.PREC == 1 && wgs > DDPM3D_PW_X3_MAX_WGS) return false;
+    return ksize == 1 && (c.PREC == 1 || c.PREC == 2 || c.PREC == 5) && c.WN == 4 && c.MT == 4 &&
+           k.in_mode == DDPM3D_IN_SAME && k.affA == nullptr && k.act == 0 && k.stats == nullptr &&
+           k.Cout % 128 == 0 && k.Cin % 32 == 0 && k.C0 % 32 == 0 && (k.C1 == 0 || s0 == s1) &&
+           (k.ksplit == 1 || k.chunks_per_split % 2 == 0);
+}
 bool ddpm3d_skinny_ok(int CinPad, int prec, int src16);   // src16: 0 fp32, 1 bf16, 2 f16
 
 // GroupNorm partial sums are STORED in fp64 (r03).  With fp32 sums the variance E[x^2] - mean^2 loses

@@ -466,6 +466,16 @@ class _Plan:
                          and (not (d.io_dtype & H.IO_SRC0_BF16) or (d.io_dtype & H.IO_HALF_IS_F16)))
                      or (pc_use.precision == H.PREC_F16X3 and not (d.io_dtype & H.IO_SRC0_BF16)))):
             tag = "conv3d_p%d_k3_skinny" % pc_use.precision
+        # (conv3d_params.h ddpm3d_pw_ok: the skip connections' register-fed 1x1 GEMM, conv1x1.hip)
+        if (pc.k == 1 and d.in_mode == H.IN_SAME and aff is None and not act and not d.stats
+                and pc.Cout % 128 == 0 and d.Cin % 32 == 0 and d.C0 % 32 == 0
+                and pc_use.precision in (H.PREC_F16X3, H.PREC_F16, H.PREC_BF16)
+                and (d.C1 == 0 or bool(d.io_dtype & H.IO_SRC0_BF16) == bool(d.io_dtype & H.IO_SRC1_BF16))):
+            ts = 8 if tile == 8 else 4
+            wgs = (N * -(-d.D // (128 // (ts * ts))) * -(-d.H // ts) * -(-d.W // ts) * (pc.Cout // 128)
+                   * max(1, need // (4 * N * d.D * d.H * d.W * pc.Cout)))
+            if pc_use.precision != H.PREC_F16X3 or wgs <= 1024:
+                tag = "conv1x1_p%d_t%d" % (pc_use.precision, tile)
         self.conv_meta[len(self.steps)] = (tag, flops)
         self.steps.append((self.eng.lib.ddpm3d_conv3d, [C.byref(d), 0]))
         return d

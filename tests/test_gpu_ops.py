@@ -775,3 +775,58 @@ def test_conv3d_skinny_last_layer(hc, precision, N, D, Hh, W, ci, co, layout):
     out, _, _ = hc.conv3d([hc.to_ndhwc(xi).cuda()], wi.cuda(), bi.cuda(), (D, Hh, W), want_stats=False,
                           precision=precision)
     assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(xi, wi, bi, padding=1))
+
+
+@pytest.mark.parametrize("precision", [1, 2, 5])
+@pytest.mark.parametrize("case", [
+    # N, D, H, W, C0, C1, Cout, residual
+    (1, 4, 16, 16, 128, 128, 128, False),    # decoder skip connection: virtual concat, 8x8 tiles
+    (2, 3, 9, 11, 64, 0, 128, True),         # ragged extents (general epilogue), two samples, residual
+    (1, 16, 4, 4, 512, 512, 384, False),     # 4x4 tiles, split over Cin (slabs + reduce kernel)
+    (1, 8, 8, 8, 96, 32, 256, True),         # two cout blocks, 4 blocks of K (3 + 1 across the concat)
+    (1, 2, 8, 8, 32, 0, 128, False),         # ONE block of K (the ring's other slots multiply zeros)
+])
+def test_conv1x1_skip_connection_kernel(hc, precision, case):
+    """conv1x1.hip (r03): the ResBlock skip connections (unet.py:173-186) -- 1x1x1 convs on raw inputs -- run
+    a register-fed GEMM that walks K in permuted 32-channel blocks.  Against torch's conv on the same
+    operands, per output channel: fp32 bar for the split-f16 mode, on bf16- / f16-rounded operands for
+    the one-MFMA modes; fp32, bf16 and f16 storage of the sources; small-integer data exactly."""
+    import guided_diffusion._hip as H
+    N, D, Hh, W, c0, c1, co, with_res = case
+    ci = c0 + c1
+    x = rnd(N, ci, D, Hh, W, seed=71) * 2.0
+    w = rnd(co, ci, 1, 1, 1, seed=72, scale=0.05)
+    b = rnd(co, seed=73)
+    res = rnd(N, co, D, Hh, W, seed=74) if with_res else None
+    for store in (torch.float32, torch.bfloat16, torch.float16):
+        if store == torch.bfloat16 and precision != 5 or store == torch.float16 and precision == 5:
+            continue          # the engine's plans: bf16 storage with bf16 arithmetic, f16 with the f16 modes
+        xs = x.to(store)
+        xv = xs.float()
+        if precision == 5:
+            xo, wo = xv.bfloat16().float(), w.bfloat16().float()
+        elif precision == 2:
+            # (the kernel rounds the SCALED operands to f16; with power-of-two scales that is the rounding of
+            # the operands themselves except in the subnormal range, which these magnitudes do not reach)
+            xo, wo = xv, w
+        else:
+            xo, wo = xv, w
+        ref = F.conv3d(xo.double(), wo.double(), b.double()).float()
+        if with_res:
+            ref = ref + res
+        srcs = [hc.to_ndhwc(xs[:, :c0]).cuda()] + ([hc.to_ndhwc(xs[:, c0:]).cuda()] if c1 else [])
+        out, _, _ = hc.conv3d(srcs, w.cuda(), b.cuda(), (D, Hh, W), precision=precision, want_stats=False,
+                              res=hc.to_ndhwc(res).cuda() if with_res else None,
+                              res_mode=H.RES_SAME if with_res else H.RES_NONE)
+        got = hc.to_ncdhw(out.cpu())
+        assert torch.isfinite(got).all()
+        tol = {1: 5e-6, 2: 2e-3, 5: 1e-5}[precision]
+        assert rel_err_per_channel(got.numpy(), ref.numpy()) < tol, (store, precision)
+    # small integers: every product and sum exact in every mode
+    g = np.random.default_rng(75)
+    xi = torch.from_numpy(g.integers(-3, 4, (N, ci, D, Hh, W)).astype(np.float32))
+    wi = torch.from_numpy((2 * g.integers(-2, 3, (co, ci, 1, 1, 1))).astype(np.float32))
+    bi = torch.from_numpy(g.integers(-5, 6, (co,)).astype(np.float32))
+    srcs = [hc.to_ndhwc(xi[:, :c0]).cuda()] + ([hc.to_ndhwc(xi[:, c0:]).cuda()] if c1 else [])
+    out, _, _ = hc.conv3d(srcs, wi.cuda(), bi.cuda(), (D, Hh, W), precision=precision, want_stats=False)
+    assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(xi, wi, bi))
