@@ -166,7 +166,7 @@ enum {
      * library picks by shape) */
     DDPM3D_HINT_WZ_ORDER_SHIFT = 12,
     DDPM3D_HINT_WZ_ORDER_MASK = 0x7000,
-    /* bits 16..21: force the split factor over Cin of a 3x3x3 conv (measurement only: no statistics,
+    /* bits 16..21: force the split factor over Cin of a conv with Cout > 64 (measurement only: no statistics,
      * workspace sized by the caller as S * output bytes; 0 = the library's own choice) */
     DDPM3D_HINT_SPLITK_SHIFT = 16,
     DDPM3D_HINT_SPLITK_MASK = 0x3F0000
