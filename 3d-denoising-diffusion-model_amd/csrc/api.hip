@@ -252,6 +252,24 @@ int ddpm3d_linear(const float* in, int rows, int K, const float* w, const float*
                     "linear");
 }
 
+int ddpm3d_pool_act(const void* src, const float* aff_a, const float* aff_b, int act, int fast_act, int N, int D,
+                    int H, int W, int C, void* out, int io_dtype, void* stream) {
+    if (!src || !out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3))
+        return fail(DDPM3D_EINVAL, "pool_act: bad arguments (C must be a multiple of 4)");
+    if ((aff_a == nullptr) != (aff_b == nullptr)) return fail(DDPM3D_EINVAL, "pool_act: aff_a/aff_b must come together");
+    if (act && !aff_a) return fail(DDPM3D_EINVAL, "pool_act: an activation needs the affine tables (pass A = 1, B = 0)");
+    if (io_dtype & ~(DDPM3D_IO_SRC0_BF16 | DDPM3D_IO_OUT_BF16 | DDPM3D_IO_HALF_IS_F16))
+        return fail(DDPM3D_EINVAL, "pool_act: io_dtype bits %#x", io_dtype);
+    if (!aligned16(src) || !aligned16(out) || (aff_a && (!aligned16(aff_a) || !aligned16(aff_b))))
+        return fail(DDPM3D_EINVAL, "pool_act: buffers must be 16-byte aligned");
+    if ((long long)N * D * H * W * (C / 4) > 0x7fffffffLL * 256)
+        return fail(DDPM3D_E2BIG, "pool_act: grid too large; split the batch");
+    return launched(ddpm3d_launch_pool_act((const float*)src, aff_a, aff_b, act, fast_act, N, D, H, W, C, (float*)out,
+                                           (io_dtype & DDPM3D_IO_SRC0_BF16) != 0, (io_dtype & DDPM3D_IO_OUT_BF16) != 0,
+                                           (io_dtype & DDPM3D_IO_HALF_IS_F16) != 0, (hipStream_t)stream),
+                    "pool_act");
+}
+
 int ddpm3d_add_embedding(float* emb, const float* table, const int64_t* idx, int rows, int dim, int num_classes,
                          void* stream) {
     if (!emb || !table || !idx || rows <= 0 || dim <= 0 || num_classes <= 0)

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "conv3d_params.h"
+#include "conv3d_load.h"   // affine_act, act_quad, half_pack
 #include "ops.h"
 
 // ------------------------------------------------------------------ packing
@@ -425,6 +426,66 @@ hipError_t ddpm3d_launch_timestep_embedding(const float* t, int rows, int dim, c
     const int total = rows * dim;
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, st, t, rows, dim,
                        freqs, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------- pooled activation (pre-pass)
+// out[n][z][y][x][c] = mean over the (1,2,2) window of act(A[n][c] * src + B[n][c]): the IN_POOL prologue of
+// ddpm3d_conv3d (conv3d_load.h halo_fetch: same window order, same SiLU) as a pass of its own, so that the
+// down ResBlocks' first conv (unet.py:238-242: h = in_conv(h_upd(in_rest(x)))) can run the Winograd-D form on
+// a plain tensor.  One thread = one output voxel x 4 channels: four 16-byte loads, one 16-byte store.
+template <bool FAST>
+__global__ __launch_bounds__(256) void pool_act_kernel(const float* __restrict__ src, const float* __restrict__ A,
+                                                       const float* __restrict__ B, int act, int N, int D, int H,
+                                                       int W, int C, float* __restrict__ out, int src16,
+                                                       int out16, int f16) {
+    const int quads = C >> 2;
+    const size_t total = (size_t)N * D * H * W * quads;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int cq = (int)(i % quads);
+    size_t v = i / quads;
+    const int x = (int)(v % W); v /= W;
+    const int y = (int)(v % H); v /= H;
+    const int z = (int)(v % D);
+    const int n = (int)(v / D);
+    const size_t Ws = 2 * (size_t)W, Hs = 2 * (size_t)H;
+    const size_t e0 = ((((size_t)n * D + z) * Hs + 2 * y) * Ws + 2 * x) * C + cq * 4;
+    f32x4 s00 = act_quad(src, e0, src16 != 0, f16 != 0);
+    f32x4 s01 = act_quad(src, e0 + C, src16 != 0, f16 != 0);
+    f32x4 s10 = act_quad(src, e0 + Ws * C, src16 != 0, f16 != 0);
+    f32x4 s11 = act_quad(src, e0 + Ws * C + C, src16 != 0, f16 != 0);
+    if (A != nullptr) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(A + (size_t)n * C + cq * 4);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(B + (size_t)n * C + cq * 4);
+        if (act) {
+            s00 = affine_act<1, FAST>(s00, ga, gb); s01 = affine_act<1, FAST>(s01, ga, gb);
+            s10 = affine_act<1, FAST>(s10, ga, gb); s11 = affine_act<1, FAST>(s11, ga, gb);
+        } else {
+            s00 = affine_act<0, FAST>(s00, ga, gb); s01 = affine_act<0, FAST>(s01, ga, gb);
+            s10 = affine_act<0, FAST>(s10, ga, gb); s11 = affine_act<0, FAST>(s11, ga, gb);
+        }
+    }
+    // AvgPool3d window order (h, w): ((s00 + s01) + s10) + s11, then * 1/4
+    const f32x4 r = (((s00 + s01) + s10) + s11) * 0.25f;
+    const size_t eo = i * 4;
+    if (out16)
+        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(out) + eo) =
+            u32x2{half_pack(r[0], r[1], f16 != 0), half_pack(r[2], r[3], f16 != 0)};
+    else
+        *reinterpret_cast<f32x4*>(out + eo) = r;
+}
+
+hipError_t ddpm3d_launch_pool_act(const float* src, const float* A, const float* B, int act, int fast, int N, int D,
+                                  int H, int W, int C, float* out, int src16, int out16, int f16, hipStream_t st) {
+    const size_t total = (size_t)N * D * H * W * (C / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (fast)
+        hipLaunchKernelGGL(pool_act_kernel<true>, dim3(blocks), dim3(256), 0, st, src, A, B, act, N, D, H, W, C, out,
+                           src16, out16, f16);
+    else
+        hipLaunchKernelGGL(pool_act_kernel<false>, dim3(blocks), dim3(256), 0, st, src, A, B, act, N, D, H, W, C, out,
+                           src16, out16, f16);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ WINOGRAD_OF = {PREC_F16X3: PREC_F16X3_WZ, PREC_F16: PREC_F16_WZ, PREC_BF16: PREC
 # ddpm3d_conv_desc.io_dtype bits: which activation tensors hold bf16
 IO_SRC0_BF16, IO_SRC1_BF16, IO_OUT_BF16, IO_RES_BF16 = 1, 2, 4, 8
 IO_HALF_IS_F16 = 16    # the flagged tensors hold IEEE f16 (the --use_fp16 storage), not bf16
-ABI_VERSION = 10
+ABI_VERSION = 11
 # ddpm3d_conv_desc.kernel_hint bits (launch orders of identical arithmetic; tests and A/B measurements)
 HINT_WSTAT_OFF, HINT_WSTAT_ON = 0x100, 0x200
 HINT_SPLITK_SHIFT = 16      # bits 16..21: forced split factor (measurement only, tools/splitk_sweep.py)
@@ -79,6 +79,8 @@ EXPORTS = {
     "ddpm3d_ddim_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float,
                                    _fp, _fp, _fp]),
     "ddpm3d_add_embedding": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp]),
+    "ddpm3d_pool_act": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp,
+                                  C.c_int, _fp]),
     "ddpm3d_mfma_probe_flops_per_iter": (C.c_double, [C.c_int]),
     "ddpm3d_mfma_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
 }

@@ -558,15 +558,31 @@ class _Plan:
         c2 = eng.conv[p + ".out_layers.3"]
         A1, B1, bnd1 = self.finalize(srcs, p + ".in_layers.0", None)
         h1 = self.new_act(c1.Cout, d, h, w)
+        aff1, act1, srcs1 = (A1, B1), H.ACT_SILU, srcs
+        pooled = None
+        if e.updown == "down" and c1.wz is not None and h >= 8 and w >= 8 and len(srcs) == 1:
+            # h_upd(in_rest(x)) as a pass of its own (ddpm3d_pool_act, fp32 result): conv1 then reads a plain
+            # tensor and runs its Winograd-D form instead of the direct kernel with the pool in its staging
+            # (128 -> 128 @ 64x32x32 from a 64^3 input: 0.244 -> 0.04 + 0.11 ms).  Same values: the pass
+            # evaluates what that staging evaluates; their bound (entry 0 of the finalize) bounds the means.
+            pooled = self.new_act(x0.C, d, h, w, fp32=True)
+            io = (H.IO_SRC0_BF16 if x0.half else 0) | (H.IO_HALF_IS_F16 if x0.buf.dtype == torch.float16 else 0)
+            self.conv_meta[len(self.steps)] = ("pool_act", 0.0)      # timed with the convs (no FLOPs of its own)
+            self.steps.append((eng.lib.ddpm3d_pool_act,
+                               [H.ptr(x0.buf), H.ptr(A1), H.ptr(B1), H.ACT_SILU, 1, self.N, d, h, w, x0.C,
+                                H.ptr(pooled.buf), io, 0]))
+            aff1, act1, srcs1, im = None, H.ACT_NONE, [pooled], H.IN_SAME
         if eng.film:
-            self.conv_step(c1, srcs, h1, aff=(A1, B1), act=H.ACT_SILU, in_mode=im, bound=(bnd1, 0, 32, 2))
+            self.conv_step(c1, srcs1, h1, aff=aff1, act=act1, in_mode=im, bound=(bnd1, 0, 32, 2))
             A2, B2, bnd2 = self.finalize([h1], p + ".out_layers.0", p)
         else:
             # additive embedding: conv1's bias is the per-sample film row slice
-            dsc = self.conv_step(c1, srcs, h1, aff=(A1, B1), act=H.ACT_SILU, in_mode=im, bias_per_n=True,
+            dsc = self.conv_step(c1, srcs1, h1, aff=aff1, act=act1, in_mode=im, bias_per_n=True,
                                  bound=(bnd1, 0, 32, 2))
             self.bias_patches.append((dsc, eng.film_off[p]))
             A2, B2, bnd2 = self.finalize([h1], p + ".out_layers.0", None)
+        if pooled is not None:
+            self.release(pooled)
         y = self.new_act(c2.Cout, d, h, w)
         skip = eng.conv.get(p + ".skip_connection")
         if skip is not None:

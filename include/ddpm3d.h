@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DDPM3D_ABI_VERSION 10
+#define DDPM3D_ABI_VERSION 11
 
 enum {
     DDPM3D_OK = 0,
@@ -265,6 +265,18 @@ int ddpm3d_timestep_embedding(const float* t, int rows, int dim, const float* fr
  * out[r][o] = bias[o] + sum_k f(in[r][k]) * w[o][k],  f = SiLU if silu_in */
 int ddpm3d_linear(const float* in, int rows, int K, const float* w, const float* bias,
                   int O, int silu_in, float* out, int out_stride, void* stream);
+
+/* The down-sampling ResBlock's h_upd(in_rest(x)) (unet.py:194-195, :238-242: GroupNorm32 + SiLU, then
+ * Downsample(use_conv=False) = AvgPool3d((1,2,2))) as a pass of its own:
+ *   out[n][z][y][x][c] = mean over (2y + {0,1}, 2x + {0,1}) of act(aff_a[n][c] * src[n][z][.][.][c] + aff_b[n][c])
+ * src = [N][D][2H][2W][C], out = [N][D][H][W][C] (H, W = the OUTPUT extents), NDHWC, C % 4 == 0; window order
+ * ((s00 + s01) + s10) + s11, then * 1/4 -- the DDPM3D_IN_POOL prologue of ddpm3d_conv3d, which computes exactly
+ * this while staging.  As a separate pass it lets the conv that follows read a plain tensor (DDPM3D_IN_SAME, no
+ * affine) and so run its Winograd-D form.  aff_a / aff_b NULL = no affine (then act must be 0); fast_act != 0 =
+ * the v_exp / v_rcp SiLU of the non-exact conv modes (what their own prologue evaluates), 0 = expf and an IEEE
+ * divide.  io_dtype: DDPM3D_IO_SRC0_BF16 / DDPM3D_IO_OUT_BF16 / DDPM3D_IO_HALF_IS_F16 as in ddpm3d_conv_desc. */
+int ddpm3d_pool_act(const void* src, const float* aff_a, const float* aff_b, int act, int fast_act, int N, int D,
+                    int H, int W, int C, void* out, int io_dtype, void* stream);
 
 /* Class conditioning (unet.py:476-478, :703-705): emb[r][:] += table[idx[r]][:] with table =
  * label_emb.weight [num_classes][dim] and idx = the batch's labels (int64, device; each in

@@ -830,3 +830,53 @@ def test_conv1x1_skip_connection_kernel(hc, precision, case):
     srcs = [hc.to_ndhwc(xi[:, :c0]).cuda()] + ([hc.to_ndhwc(xi[:, c0:]).cuda()] if c1 else [])
     out, _, _ = hc.conv3d(srcs, wi.cuda(), bi.cuda(), (D, Hh, W), precision=precision, want_stats=False)
     assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(xi, wi, bi))
+
+
+@pytest.mark.parametrize("store", ["f32", "bf16", "f16"])
+def test_pool_act_prepass(hc, store):
+    """ddpm3d_pool_act (ABI 11): AvgPool3d((1,2,2)) of SiLU(A x + B) -- the down ResBlock's
+    h_upd(in_rest(x)) (unet.py:194-195, :238-242) -- against torch, for fp32 / bf16 / f16 sources and
+    outputs, exact and fast SiLU; and against the conv's own IN_POOL prologue: an identity 1x1 conv
+    on the pooled input must give the SAME tensor bit for bit (exact mode, same window order)."""
+    import ctypes as C
+    import guided_diffusion._hip as H
+    lib = H.load()
+    N, D, Hh, W, Cn = 2, 3, 6, 10, 32
+    x = rnd(N, Cn, D, 2 * Hh, 2 * W, seed=81) * 2.0
+    A = 1.0 + 0.1 * rnd(N, Cn, seed=82)
+    B = 0.1 * rnd(N, Cn, seed=83)
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[store]
+    xs = hc.to_ndhwc(x).to(dt).cuda()
+    xv = hc.to_ncdhw(xs.float().cpu())
+    ref = F.avg_pool3d(F.silu(xv * A[:, :, None, None, None] + B[:, :, None, None, None]), (1, 2, 2))
+    io_in = 0 if store == "f32" else (H.IO_SRC0_BF16 | (H.IO_HALF_IS_F16 if store == "f16" else 0))
+    Ad, Bd = A.cuda(), B.cuda()
+    for fast in (0, 1):
+        for out_half in ((False,) if store == "f32" else (False, True)):
+            io = io_in | ((H.IO_OUT_BF16 | (H.IO_HALF_IS_F16 if store == "f16" else 0)) if out_half else 0)
+            out = torch.full((N, D, Hh, W, Cn), float("nan"), dtype=dt if out_half else torch.float32, device="cuda")
+            H.check(lib.ddpm3d_pool_act(H.ptr(xs), H.ptr(Ad), H.ptr(Bd), H.ACT_SILU, fast, N, D, Hh, W, Cn, H.ptr(out),
+                                        io, H.stream()))
+            torch.cuda.synchronize()
+            got = hc.to_ncdhw(out.float().cpu())
+            tol = (2.0 ** -8 if store == "bf16" else 2.0 ** -10) if out_half else (2e-6 if fast else 5e-7)
+            assert rel_err(got.numpy(), ref.numpy()) < tol, (store, fast, out_half)
+    # no affine, no activation: the plain average, exactly
+    out = torch.empty(N, D, Hh, W, Cn, dtype=torch.float32, device="cuda")
+    H.check(lib.ddpm3d_pool_act(H.ptr(xs), 0, 0, H.ACT_NONE, 0, N, D, Hh, W, Cn, H.ptr(out), io_in, H.stream()))
+    v = xs.float().cpu()
+    plain = (((v[:, :, 0::2, 0::2] + v[:, :, 0::2, 1::2]) + v[:, :, 1::2, 0::2]) + v[:, :, 1::2, 1::2]) * 0.25
+    assert torch.equal(out.cpu(), plain)
+    # the conv's own pooled prologue evaluates the same numbers: identity 1x1 conv, exact mode
+    if store == "f32":
+        w = torch.eye(Cn).reshape(Cn, Cn, 1, 1, 1)
+        b = torch.zeros(Cn)
+        fused, _, _ = hc.conv3d([xs], w.cuda(), b.cuda(), (D, Hh, W), in_mode=H.IN_POOL, aff=(Ad, Bd),
+                                act=H.ACT_SILU, precision=0, want_stats=False)
+        H.check(lib.ddpm3d_pool_act(H.ptr(xs), H.ptr(Ad), H.ptr(Bd), H.ACT_SILU, 0, N, D, Hh, W, Cn, H.ptr(out), 0,
+                                    H.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), fused.cpu())
+    # rejected: C not a multiple of 4, an activation without the affine
+    assert lib.ddpm3d_pool_act(H.ptr(xs), 0, 0, H.ACT_NONE, 0, N, D, Hh, W, 30, H.ptr(out), io_in, H.stream()) == H.E_INVAL
+    assert lib.ddpm3d_pool_act(H.ptr(xs), 0, 0, H.ACT_SILU, 0, N, D, Hh, W, Cn, H.ptr(out), io_in, H.stream()) == H.E_INVAL
