@@ -119,9 +119,9 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
                                     : c.tilesZ * c.tilesY * c.tilesX * (4 / c.WN);   // (the reduce kernel's grid)
     }
     if (prec_wz(d->precision) &&
-        !(wz_layer_ok(d->Cout, d->Cin, d->ksize) && c.TXL == 3 && c.WN == 4 && c.MT == 4 &&
+        !(wz_layer_ok(d->Cout, d->Cin, d->ksize) && c.WN == 4 && c.MT == 4 &&
           (d->in_mode == DDPM3D_IN_SAME || d->in_mode == DDPM3D_IN_UP)))
-        return fail(DDPM3D_ENOSUP, "conv3d: the Winograd-D form needs ksize 3, Cout %% 128 == 0, H and W >= 8 "
+        return fail(DDPM3D_ENOSUP, "conv3d: the Winograd-D form needs ksize 3, Cout %% 128 == 0 "
                                    "and input mode SAME or UP; use the F16X3 packing for this call");
     if (c.S > 1 && (!d->workspace || d->workspace_bytes < c.workspace_bytes || !aligned16(d->workspace)))
         return fail(DDPM3D_EINVAL, "conv3d: this shape is split %d-way over Cin and needs %zu bytes of "

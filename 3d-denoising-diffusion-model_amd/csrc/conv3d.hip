@@ -505,6 +505,17 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     // parameter).
     // f16x3: the issue order of a tap (conv3d_wz.h, IL): one order for every shape since r03
     // (profiles/r03_layer_ab_wz_issue_order.txt; r02 had picked between 0 and 1 by shape).
+    if (c.TXL == 2) {
+        // 4x4x8 tiles (the levels below 8x8: r03).  One issue order; the image is 56 KB
+        constexpr size_t lds4 = (size_t)WzGeomT<4>::BUF;
+        if (c.PREC == DDPM3D_PREC_F16_WZ)
+            hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16, 0, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds4, st, k);
+        else if (c.PREC == DDPM3D_PREC_BF16_WZ)
+            hipLaunchKernelGGL((conv3d_wz_kernel<WZ_BF16, 0, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds4, st, k);
+        else
+            hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 4, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds4, st, k);
+        return hipGetLastError();
+    }
     if (c.PREC == DDPM3D_PREC_F16_WZ)
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     else if (c.PREC == DDPM3D_PREC_BF16_WZ)

@@ -59,7 +59,15 @@ __device__ __forceinline__ void quad_transpose(float (&a)[4], bool b0, bool b1) 
 // row = (reg&3) + 8*(reg>>2) + 4*half.
 // inv_act = 1 / activation scale of this sample (split-f16 modes; 1 in the exact mode)
 // WIDE: the 16-byte store form below (one-MFMA modes), or the four-byte form
-template <int PREC, int WM, int MT, int TXL, int TYL, bool WIDE = false>
+// ZPAIRS (conv3d_wz.h on 4x4x8 tiles): accumulator u = zbit*2 + t holds, in its rows 0-15 / 16-31, output plane
+// zbit of the z-pairs 2t / 2t+1 -- depth 4t + 2 (row >> 4) + zbit instead of the plain 2u + (row >> 4)
+template <int TXL, int TYL, bool ZPAIRS>
+__device__ __forceinline__ constexpr int epi_tz(int m) {
+    const int r = m >> (TXL + TYL);
+    return ZPAIRS ? 4 * ((r >> 1) & 1) + 2 * (r & 1) + (r >> 2) : r;
+}
+
+template <int PREC, int WM, int MT, int TXL, int TYL, bool WIDE = false, bool ZPAIRS = false>
 // pre_ws / pre_bias (pre = true): p.wscale[cout] and the lane's bias, loaded by the caller at kernel
 // START (conv3d_wz.h): at the epilogue's start they are a dependent global load -- ~2k cycles at the
 // head of a phase in which the wave issues no MFMA
@@ -154,7 +162,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int m0 = (wm * MT + t) * 32 + 8 * g;
-                            const int ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL), tx = m0 & (TX - 1);
+                            const int ty = (m0 >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m0), tx = m0 & (TX - 1);
                             const unsigned so = (unsigned)((tz * p.H + ty) * p.W + tx) * rstride;
                             if (r16) rq[g] = half4_expand(__builtin_amdgcn_raw_buffer_load_b64(rrsrc, wr, so, 0), f16);
                             else rq[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, wr, so, 0));
@@ -180,7 +188,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                             }
                         }
                         const int m0 = (wm * MT + t) * 32 + 8 * g;
-                        const int ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL), tx = m0 & (TX - 1);
+                        const int ty = (m0 >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m0), tx = m0 & (TX - 1);
                         const unsigned so = (unsigned)((tz * p.H + ty) * p.W + tx) * cstride;
                         if (o16)
                             __builtin_amdgcn_raw_buffer_store_b64(u32x2{half_pack(a[0], a[1], f16), half_pack(a[2], a[3], f16)}, drsrc, wv, so, 0);
@@ -220,7 +228,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
-                    const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
+                    const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m0);
                     soff[reg] = (unsigned)((tz * p.H + ty) * p.W + tx) * cstride;
                 }
                 float r[16];
@@ -228,14 +236,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
-                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
+                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m0);
                         r[reg] = rload((unsigned)((tz * p.H + ty) * p.W + tx) * rstride);
                     }
                 } else if (rm == DDPM3D_RES_UP) {
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
-                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
+                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m0);
                         r[reg] = rload((unsigned)((tz * rH + (ty >> 1)) * rW + (tx >> 1)) * rstride);
                     }
                 } else if (rm == DDPM3D_RES_POOL) {
@@ -243,7 +251,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) {
                         const int m0 = (wm * MT + t) * 32 + (reg & 3) + 8 * (reg >> 2);
-                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = m0 >> (TXL + TYL);
+                        const int tx = m0 & (TX - 1), ty = (m0 >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m0);
                         const unsigned so = (unsigned)((tz * rH + 2 * ty) * rW + 2 * tx) * rstride;
                         const float r00 = rload(so), r01 = rload(so + rstride);
                         const float r10 = rload(so + rW * rstride), r11 = rload(so + (rW + 1) * rstride);
@@ -288,7 +296,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
                 const int m = (wm * MT + t) * 32 + row;
-                const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
+                const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m);
                 const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
                 if (cvalid && z < p.D && y < p.H && x < p.W)
                     slab[(((size_t)z * p.H + y) * p.W + x) * p.Cout + cout] =
@@ -307,7 +315,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
         for (int reg = 0; reg < 16; ++reg) {
             const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
             const int m = (wm * MT + t) * 32 + row;
-            const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = m >> (TXL + TYL);
+            const int tx = m & (TX - 1), ty = (m >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m);
             const int z = z0 + tz, y = y0 + ty, x = x0 + tx;
             const bool ok = cvalid && z < p.D && y < p.H && x < p.W;
             if (ok) {

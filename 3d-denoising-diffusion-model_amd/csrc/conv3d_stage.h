@@ -1,4 +1,4 @@
-// Lean staging of one (8x8x2-output tile, 16-channel chunk) item of the Winograd-D convolutions:
+// Lean staging of one (128-voxel output tile -- 8x8x2 or 4x4x8 --, 16-channel chunk) item of the Winograd-D convolutions:
 // raw input planes -> GroupNorm/FiLM affine -> SiLU -> F(2,3) input transform along depth ->
 // f16 hi/lo split -> LDS image, for conv3d_wz.h (split_pair also serves conv3d_skinny.hip).
 //
@@ -36,34 +36,46 @@ __device__ __forceinline__ void split_pair(float s0, float s1, unsigned& hi, uns
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(l0), "v"(l1));
 }
 
-// geometry of the 8x8x2 tile's LDS image (4 transformed planes of 10x10 voxels, 80 B per voxel)
-struct WzGeom {
+// Geometry of a workgroup tile's LDS image: TXY x TXY (y, x) positions x NZP z-pairs = 128 output voxels.
+//   TXY = 8: ONE z-pair (8x8x2): 4 transformed planes of 10x10 voxels, 80 B per voxel
+//   TXY = 4: FOUR z-pairs (4x4x8, the 64x4x4 level; r03): 4 pair images of 4 transformed planes of 6x6 voxels each;
+//            the pairs' input planes overlap, so an item is 10 input planes
+// A pair image's size is a multiple of 256 B, so rows of different pairs keep the bank residues of LdsGeom.
+template <int TXY>
+struct WzGeomT {
     static constexpr int CK = DDPM3D_CONV_CK;
-    static constexpr int HX = 10, HY = 10, NP = 4, VS = 5;
-    static constexpr int RY = LdsGeom<8, HX, HY>::RY;
-    static constexpr int RZ = LdsGeom<8, HX, HY>::RZ;
-    static constexpr int BUF = NP * RZ * 16;          // bytes of one image
-    static constexpr int HC = HX * HY * (CK / 4);     // staging slots: (y, x, channel quad)
-    static constexpr int NL = (HC + 255) / 256;       // slots per staging thread
+    static constexpr int TX = TXY, HX = TXY + 2, HY = TXY + 2, NP = 4, VS = 5;
+    static constexpr int NZP = TXY == 8 ? 1 : 4;       // z-pairs per tile
+    static constexpr int NPL = 2 * NZP + 2;            // input planes per item
+    static constexpr int RY = LdsGeom<TXY, HX, HY>::RY;
+    static constexpr int RZ = LdsGeom<TXY, HX, HY>::RZ;
+    static constexpr int PAIR = NP * RZ * 16;          // bytes of one z-pair's image
+    static constexpr int BUF = NZP * PAIR;             // bytes of the tile's image
+    static constexpr int HC = HX * HY * (CK / 4);      // staging slots: (y, x, channel quad)
+    static constexpr int NL = (HC + 255) / 256;        // slots per staging thread
 };
+typedef WzGeomT<8> WzGeom;
 
 // Per-thread, launch-invariant part of the staging (256 staging threads, thread = lt).
-struct StageLane {
-    unsigned vo0[WzGeom::NL], vo1[WzGeom::NL];   // byte offset of slot i's voxel at plane zb in src0 / src1
+template <class G>
+struct StageLaneT {
+    unsigned vo0[G::NL], vo1[G::NL];             // byte offset of slot i's voxel at plane zb in src0 / src1
     unsigned es0, es1;                           // bytes per element of src0 / src1 (4, or 2 = bf16 / f16)
     bool f16;                                    // the 2-byte elements are IEEE f16, not bf16
-    int lds[WzGeom::NL];                         // byte offset of slot i inside a plane of the image
-    bool ok[WzGeom::NL];                         // slot exists and its (y, x) lies inside the volume
+    int lds[G::NL];                              // byte offset of slot i inside a plane of the image
+    bool ok[G::NL];                              // slot exists and its (y, x) lies inside the volume
     unsigned plane0, plane1;                     // bytes per z-plane of src0 / src1
     int zb;                                      // first source plane the offsets refer to
     float scale;                                 // activation scale S of this sample (power of two)
     float km, ka;                                // sigmoid exponent = fma(yS, km, ka)
     int q;
 };
+typedef StageLaneT<WzGeom> StageLane;
 
 // zb = the lowest input plane any item of this workgroup reads (clamped to 0)
-__device__ __forceinline__ StageLane stage_lane(const ConvK& p, int lt, int n, int y0, int x0, int zb, float scale) {
-    StageLane s;
+template <class G = WzGeom>
+__device__ __forceinline__ StageLaneT<G> stage_lane(const ConvK& p, int lt, int n, int y0, int x0, int zb, float scale) {
+    StageLaneT<G> s;
     s.scale = scale;
     const int up = p.in_mode == DDPM3D_IN_UP ? 1 : 0;
     const int Hs = p.H >> up, Ws = p.W >> up;
@@ -78,29 +90,31 @@ __device__ __forceinline__ StageLane stage_lane(const ConvK& p, int lt, int n, i
     s.km = p.act ? -1.44269504088896341f / scale : 0.0f;
     s.ka = p.act ? 0.0f : -126.0f;
 #pragma unroll
-    for (int i = 0; i < WzGeom::NL; ++i) {
+    for (int i = 0; i < G::NL; ++i) {
         const int idx = lt + i * 256;
         const int hyx = idx >> 2;
-        const int hy = hyx / WzGeom::HX, hx = hyx - hy * WzGeom::HX;
+        const int hy = hyx / G::HX, hx = hyx - hy * G::HX;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        s.ok[i] = idx < WzGeom::HC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        s.ok[i] = idx < G::HC && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
         const unsigned vox = (unsigned)(((n * p.D + zb) * Hs + (y >> up)) * Ws + (x >> up));
         s.vo0[i] = s.ok[i] ? (vox * (unsigned)p.C0 + s.q * 4u) * s.es0 : DDPM3D_OOB_OFFSET;
         s.vo1[i] = s.ok[i] ? (vox * (unsigned)p.C1 + s.q * 4u) * s.es1 : DDPM3D_OOB_OFFSET;
-        s.lds[i] = (hy * WzGeom::RY + hx * WzGeom::VS) * 16 + s.q * 8;
+        s.lds[i] = (hy * G::RY + hx * G::VS) * 16 + s.q * 8;
     }
     return s;
 }
 
 // Slots of halo voxels outside H x W are zero for every item: written once, never again.
-__device__ __forceinline__ void stage_zero_border(const StageLane& s, unsigned char* lds_images, int nimages, int lt) {
+// nimages = tile images at lds_images (each G::NZP pair images)
+template <class G>
+__device__ __forceinline__ void stage_zero_border(const StageLaneT<G>& s, unsigned char* lds_images, int nimages, int lt) {
 #pragma unroll
-    for (int i = 0; i < WzGeom::NL; ++i) {
-        if (lt + i * 256 < WzGeom::HC && !s.ok[i]) {
-            for (int b = 0; b < nimages; ++b)
+    for (int i = 0; i < G::NL; ++i) {
+        if (lt + i * 256 < G::HC && !s.ok[i]) {
+            for (int b = 0; b < nimages * G::NZP; ++b)
 #pragma unroll
-                for (int j = 0; j < WzGeom::NP; ++j) {
-                    unsigned char* v = lds_images + b * WzGeom::BUF + j * WzGeom::RZ * 16 + s.lds[i];
+                for (int j = 0; j < G::NP; ++j) {
+                    unsigned char* v = lds_images + b * G::PAIR + j * G::RZ * 16 + s.lds[i];
                     *reinterpret_cast<u32x2*>(v) = u32x2{0u, 0u};
                     *reinterpret_cast<u32x2*>(v + 32) = u32x2{0u, 0u};
                 }
@@ -110,19 +124,19 @@ __device__ __forceinline__ void stage_zero_border(const StageLane& s, unsigned c
 
 // One item's raw data: the NPL = 2 * NZP + 2 input planes z0-1 .. z0+2*NZP of the thread's slots (NZP
 // consecutive z-pairs share their inner planes) + the chunk's affine.
-template <int NPL>
+template <class G>
 struct StageRawT {
-    u32x4 v[WzGeom::NL][NPL];   // raw bits: four fp32, or four bf16 in the low half
+    u32x4 v[G::NL][G::NPL];   // raw bits: four fp32, or four bf16 in the low half
     f32x4 ga, gb;
     unsigned zmask;   // bit k: plane z0 - 1 + k lies inside the volume (uniform)
     bool b16;         // this item's source holds bf16 (uniform)
 };
-typedef StageRawT<4> StageRaw;
+typedef StageRawT<WzGeom> StageRaw;
 
 // issue the loads of item (first z-pair z0, channel chunk `chunk`)
-template <int NPL>
-__device__ __forceinline__ void stage_issue(const ConvK& p, const StageLane& s, StageRawT<NPL>& r, int n, int z0, int chunk) {
-    const int c0 = chunk * WzGeom::CK;
+template <class G>
+__device__ __forceinline__ void stage_issue(const ConvK& p, const StageLaneT<G>& s, StageRawT<G>& r, int n, int z0, int chunk) {
+    const int c0 = chunk * G::CK;
     const bool from0 = c0 < p.C0;
     const __amdgpu_buffer_rsrc_t rs = from0 ? make_rsrc(p.src0, p.src0_bytes) : make_rsrc(p.src1, p.src1_bytes);
     const unsigned plane = from0 ? s.plane0 : s.plane1;
@@ -130,13 +144,13 @@ __device__ __forceinline__ void stage_issue(const ConvK& p, const StageLane& s, 
     r.b16 = (from0 ? s.es0 : s.es1) == 2u;
     r.zmask = 0;
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) {
+    for (int k = 0; k < G::NPL; ++k) {
         const int z = z0 - 1 + k;
         if ((unsigned)z < (unsigned)p.D) {
             r.zmask |= 1u << k;
             const unsigned soff = cb4 + (unsigned)(z - s.zb) * plane;
 #pragma unroll
-            for (int i = 0; i < WzGeom::NL; ++i)
+            for (int i = 0; i < G::NL; ++i)
                 r.v[i][k] = buffer_load_quad(rs, from0 ? s.vo0[i] : s.vo1[i], soff, r.b16);
         }
     }
@@ -149,11 +163,10 @@ __device__ __forceinline__ void stage_issue(const ConvK& p, const StageLane& s, 
     }
 }
 
-// raw -> image(s) at `buf` (z-pair zp at buf + zp * WzGeom::BUF).  MODE WZ_F16 keeps only the hi
+// raw -> image at `buf` (z-pair zp at buf + zp * G::PAIR).  MODE WZ_F16 keeps only the hi
 // halves; WZ_BF16 stores bf16 pairs in the hi slots (s.scale is 1 then).
-template <int MODE, int NPL = 4>
-__device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<NPL>& r, unsigned char* buf) {
-    constexpr int NZP = (NPL - 2) / 2;
+template <int MODE, class G>
+__device__ __forceinline__ void stage_write(const StageLaneT<G>& s, const StageRawT<G>& r, unsigned char* buf) {
     float sa[4], sb[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -161,37 +174,42 @@ __device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<
         sb[c] = r.gb[c] * s.scale;
     }
 #pragma unroll
-    for (int i = 0; i < WzGeom::NL; ++i) {
-        float d[NPL][4];   // S * act(A x + B) of the input planes
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
+    for (int i = 0; i < G::NL; ++i) {
+        // S * act(A x + B) of input plane k
+        auto plane = [&](const int k, float (&d)[4]) {
             if (r.zmask & (1u << k)) {
                 const f32x4 x = quad_bits_expand(r.v[i][k], r.b16, s.f16);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float ys = __builtin_fmaf(x[c], sa[c], sb[c]);
                     const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(ys, s.km, s.ka));
-                    d[k][c] = ys * __builtin_amdgcn_rcpf(1.0f + e);
+                    d[c] = ys * __builtin_amdgcn_rcpf(1.0f + e);
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) d[k][c] = 0.0f;
+                for (int c = 0; c < 4; ++c) d[c] = 0.0f;
             }
-        }
-        if (s.ok[i]) {
+        };
+        // a window of four planes slides over the item's z-pairs (two new planes per pair)
+        float d[4][4];
+        plane(0, d[0]);
+        plane(1, d[1]);
 #pragma unroll
-            for (int zp = 0; zp < NZP; ++zp)
+        for (int zp = 0; zp < G::NZP; ++zp) {
+            const int a = (2 * zp) & 3, b1 = (2 * zp + 1) & 3, b2 = (2 * zp + 2) & 3, b3 = (2 * zp + 3) & 3;
+            plane(2 * zp + 2, d[b2]);
+            plane(2 * zp + 3, d[b3]);
+            if (s.ok[i]) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int b = 2 * zp;
                     float v[4];   // |v| < 2^15 by the choice of S: nothing to clamp
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        v[c] = j == 0 ? d[b][c] - d[b + 2][c]
-                             : j == 1 ? d[b + 1][c] + d[b + 2][c]
-                             : j == 2 ? d[b + 2][c] - d[b + 1][c]
-                                      : d[b + 1][c] - d[b + 3][c];
-                    unsigned char* vrow = buf + zp * WzGeom::BUF + j * WzGeom::RZ * 16 + s.lds[i];
+                        v[c] = j == 0 ? d[a][c] - d[b2][c]
+                             : j == 1 ? d[b1][c] + d[b2][c]
+                             : j == 2 ? d[b2][c] - d[b1][c]
+                                      : d[b1][c] - d[b3][c];
+                    unsigned char* vrow = buf + zp * G::PAIR + j * G::RZ * 16 + s.lds[i];
                     if constexpr (MODE == WZ_BF16) {
                         *reinterpret_cast<u32x2*>(vrow) = u32x2{bf16_pack(v[0], v[1]), bf16_pack(v[2], v[3])};
                     } else {
@@ -202,6 +220,7 @@ __device__ __forceinline__ void stage_write(const StageLane& s, const StageRawT<
                         if (MODE == WZ_F16X3) *reinterpret_cast<u32x2*>(vrow + 32) = u32x2{l0, l1};
                     }
                 }
+            }
         }
     }
 }

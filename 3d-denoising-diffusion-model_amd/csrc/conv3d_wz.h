@@ -42,12 +42,16 @@
 #define WZ_STAMP(i) do { } while (0)
 #endif
 
-template <int MODE, int IL = 0>
+// TXY = 8: 8x8x2 tiles (H, W >= 8).  TXY = 4 (r03): 4x4x8 tiles = four z-pairs of 16 (y, x) positions, for the
+// 64x4x4 level, which the direct kernel's 4x4 tiles ran at 1.5x the MFMAs (conv3d_stage.h WzGeomT); a 32-row
+// MFMA tile is then two z-pairs' worth of one transformed plane, the tap loop below is the same code.
+template <int MODE, int IL = 0, int TXY = 8>
 __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
+    typedef WzGeomT<TXY> G;
     constexpr bool X3 = MODE == WZ_F16X3;
     constexpr int CK = DDPM3D_CONV_CK, NT = 36;
-    constexpr int TX = 8, TXL = 3, TYL = 3;
-    constexpr int VS = WzGeom::VS, RY = WzGeom::RY, RZ = WzGeom::RZ;
+    constexpr int TX = TXY, TXL = TXY == 8 ? 3 : 2, TYL = TXL;
+    constexpr int VS = G::VS, RY = G::RY, RZ = G::RZ;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
 #ifdef DDPM3D_WZ_STAMPS
-    unsigned long long* wz_stamps = reinterpret_cast<unsigned long long*>(lds + WzGeom::BUF) + wn * WZ_NSTAMP;
+    unsigned long long* wz_stamps = reinterpret_cast<unsigned long long*>(lds + G::BUF) + wn * WZ_NSTAMP;
     WZ_STAMP(0);
 #endif
 
@@ -66,14 +70,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     const int ty_i = tile % p.tilesY; tile /= p.tilesY;
     const int tz_i = tile % p.tilesZ; tile /= p.tilesZ;
     const int n = tile;
-    const int x0 = tx_i * TX, y0 = ty_i * 8, z0 = tz_i * 2;
+    const int x0 = tx_i * TX, y0 = ty_i * TX, z0 = tz_i * 2 * G::NZP;
 
-    // GEMM rows of this wave: the 64 (y, x) positions of the tile, two 32-row MFMA tiles
+    // GEMM rows of this wave, two 32-row MFMA tiles: the 64 (y, x) positions of the 8x8 tile, or the 16
+    // positions of the 4x4 tile in each of its four z-pairs (row m: pair m >> 4)
     int arow[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int m = t * 32 + (lane & 31);
-        arow[t] = ((m >> TXL) * RY + (m & (TX - 1)) * VS + half) * 16;
+        if constexpr (TXY == 8)
+            arow[t] = ((m >> TXL) * RY + (m & (TX - 1)) * VS + half) * 16;
+        else
+            arow[t] = (m >> 4) * G::PAIR + (((m >> TXL) & (TX - 1)) * RY + (m & (TX - 1)) * VS + half) * 16;
     }
 
     const int cout = wg.cy * 128 + wn * 32 + (lane & 31);
@@ -100,9 +108,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
 
     ActScale asc = {1.0f, 1.0f};
     if constexpr (MODE != WZ_BF16) asc = act_scale(p, n, 2.0f);   // the input transform adds two planes
-    const StageLane sl = stage_lane(p, tid, n, y0, x0, max(z0 - 1, 0), asc.s);
+    const StageLaneT<G> sl = stage_lane<G>(p, tid, n, y0, x0, max(z0 - 1, 0), asc.s);
     stage_zero_border(sl, lds, 1, tid);
-    StageRaw raw;
+    StageRawT<G> raw;
     if (chunk_begin < chunk_end) stage_issue(p, sl, raw, n, z0, chunk_begin);
     WZ_STAMP(1);
 
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         WZ_STAMP(2 + (chunk - chunk_begin) * 5);
         __syncthreads();
         WZ_STAMP(3 + (chunk - chunk_begin) * 5);
-        stage_write<MODE>(sl, raw, lds);
+        stage_write<MODE, G>(sl, raw, lds);
         WZ_STAMP(4 + (chunk - chunk_begin) * 5);
         __syncthreads();
         WZ_STAMP(5 + (chunk - chunk_begin) * 5);
@@ -221,8 +229,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     }
     WZ_STAMP(42);
 
-    // ---- output transform (register-local), then the common epilogue on the 8x8x2 tile:
-    // virtual accumulator u = zbit*2 + t covers rows m = u*32 + row -> (tz = zbit, ty, tx)
+    // ---- output transform (register-local), then the common epilogue on the tile:
+    // virtual accumulator u = zbit*2 + t covers rows m = u*32 + row -> 8x8x2: (tz = zbit, ty, tx); 4x4x8: the
+    // two z-pairs 2t and 2t+1 of row tile t, i.e. tz = 4t + 2 (row >> 4) + zbit (conv_epilogue's ZPAIRS map)
     f32x16 outv[4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -230,8 +239,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         outv[2 + t] = acc[1][t] - acc[2][t] - acc[3][t];
     }
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<1, 1, 4, TXL, TYL, MODE != WZ_F16X3>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split, asc.inv,
-                                                       true, pre_ws, pre_bias);
+    conv_epilogue<1, 1, 4, TXL, TYL, MODE != WZ_F16X3, TXY == 4>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split,
+                                                                 asc.inv, true, pre_ws, pre_bias);
 #ifdef DDPM3D_WZ_STAMPS
     WZ_STAMP(43);
     if (lane == 0) {

@@ -433,8 +433,7 @@ class _Plan:
                 raise RuntimeError("conv_step without an input bound")
             d.in_bound = bound[0].data_ptr() + 4 * bound[1]
             d.in_bound_count, d.in_bound_stride = bound[2], bound[3]
-        if (pc.wz is not None and not planar and in_mode in (H.IN_SAME, H.IN_UP)
-                and d.H >= 8 and d.W >= 8):
+        if pc.wz is not None and not planar and in_mode in (H.IN_SAME, H.IN_UP):
             pc_use = pc.wz       # Winograd-D form: same layer, same arithmetic, 2/3 of the MFMAs
         else:
             pc_use = pc
@@ -560,7 +559,7 @@ class _Plan:
         h1 = self.new_act(c1.Cout, d, h, w)
         aff1, act1, srcs1 = (A1, B1), H.ACT_SILU, srcs
         pooled = None
-        if e.updown == "down" and c1.wz is not None and h >= 8 and w >= 8 and len(srcs) == 1:
+        if e.updown == "down" and c1.wz is not None and len(srcs) == 1:
             # h_upd(in_rest(x)) as a pass of its own (ddpm3d_pool_act, fp32 result): conv1 then reads a plain
             # tensor and runs its Winograd-D form instead of the direct kernel with the pool in its staging
             # (128 -> 128 @ 64x32x32 from a 64^3 input: 0.244 -> 0.04 + 0.11 ms).  Same values: the pass

@@ -194,8 +194,9 @@ enum {
     /* F16X3 arithmetic on the Winograd F(2,3)-along-depth form of a 3x3x3 conv: 4 products
      * per two outputs instead of 6 (the weights are transformed at pack time, the inputs
      * while they are staged, the outputs in the epilogue).  Available for ksize 3, Cout a
-     * multiple of 128, H and W >= 8, input modes SAME / UP; other calls return DDPM3D_ENOSUP
-     * and must use the F16X3 packing of the same weights. */
+     * multiple of 128, input modes SAME / UP (8x8x2 tiles where H and W >= 8, 4x4x8 tiles -- four
+     * z-pairs per workgroup -- below); other calls return DDPM3D_ENOSUP and must use the F16X3
+     * packing of the same weights. */
     DDPM3D_PREC_F16X3_WZ = 3,
     /* F16 arithmetic (one MFMA per product on f16-rounded operands, as DDPM3D_PREC_F16) on the
      * same Winograd-D form and the same packed image as DDPM3D_PREC_F16X3_WZ (its hi halves);

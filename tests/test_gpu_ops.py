@@ -110,6 +110,9 @@ def test_conv3d_f16x3_accuracy_is_fp32_grade(hc):
     (2, 5, 8, 24, 32, 256),      # odd D (last z-pair half valid), batch 2, two cout blocks
     (1, 1, 9, 12, 16, 128),      # D = 1, ragged H / W
     (1, 64, 8, 8, 256, 384),     # the published net's 8x8 level: split-K + reduce kernel
+    (1, 64, 4, 4, 512, 512),     # its 4x4 level: 4x4x8 tiles (four z-pairs per tile), split-K + reduce
+    (2, 5, 4, 6, 32, 128),       # 4x4x8 tiles, ragged in all three extents (D = 5: pairs 2, 3 of the tile empty / half)
+    (1, 11, 7, 3, 16, 256),      # W < 4, D not a multiple of 8, two cout blocks
 ])
 def test_conv3d_winograd_depth_form(hc, N, D, Hh, W, ci, co):
     """precision 3: f16x3 arithmetic on the Winograd F(2,3)-along-depth form (weights transformed
@@ -148,11 +151,27 @@ def test_conv3d_winograd_depth_exact_and_fused_paths(hc):
                               res_mode=H.RES_UP, precision=3)
     assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
     check_stats(stats, ref)
+    # the same on 4x4x8 tiles (H, W < 8; r03): exact integers over a whole tile column, and the up-sampled
+    # block path from a 2x3 grid
+    x4 = torch.from_numpy(g.integers(-3, 4, (1, 16, 19, 4, 4)).astype(np.float32))
+    out, _, _ = hc.conv3d([hc.to_ndhwc(x4).cuda()], w.cuda(), b.cuda(), (19, 4, 4), precision=3)
+    assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(x4, w, b, padding=1))
+    xa, xb = rnd(1, 32, 9, 2, 3, seed=11), rnd(1, 32, 9, 2, 3, seed=12)
+    xc = torch.cat([xa, xb], 1)
+    r = rnd(1, 128, 9, 2, 3, seed=18)
+    ref = F.conv3d(up(F.silu(F.group_norm(xc, 32, gamma, beta, 1e-5))), w2, b2, padding=1) + up(r)
+    A, B = _gn_affine(hc, [xa, xb], gamma, beta)
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(xa).cuda(), hc.to_ndhwc(xb).cuda()], w2.cuda(), b2.cuda(), (9, 4, 6),
+                              in_mode=H.IN_UP, aff=(A, B), act=H.ACT_SILU, res=hc.to_ndhwc(r).cuda(),
+                              res_mode=H.RES_UP, precision=3)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)
     # shapes / modes the form does not cover are refused, not silently mis-computed
     lib = H.load()
     assert lib.ddpm3d_packed_weight_bytes(96, 32, 3, 3) == 0
     with pytest.raises(RuntimeError, match="Winograd"):
-        hc.conv3d([hc.to_ndhwc(rnd(1, 16, 4, 4, 4)).cuda()], w.cuda(), b.cuda(), (4, 4, 4), precision=3)
+        hc.conv3d([hc.to_ndhwc(rnd(1, 16, 4, 8, 8)).cuda()], w.cuda(), b.cuda(), (4, 4, 4), in_mode=H.IN_POOL,
+                  precision=3)
 
 
 def test_conv3d_f16_mode_is_half_precision_grade(hc):
@@ -178,6 +197,8 @@ def test_conv3d_f16_mode_is_half_precision_grade(hc):
     (1, 4, 16, 16, 64, 128),
     (2, 5, 8, 24, 32, 256),      # odd D, batch 2, two cout blocks
     (1, 64, 8, 8, 256, 384),     # split-K + reduce kernel
+    (1, 64, 4, 4, 256, 128),     # 4x4x8 tiles + split-K
+    (2, 7, 5, 4, 32, 128),       # 4x4x8 tiles, ragged
 ])
 def test_conv3d_f16_winograd_depth_form(hc, N, D, Hh, W, ci, co):
     """precision 4: the f16 mode (one MFMA per product) on the Winograd-D form.  The transformed
@@ -209,6 +230,8 @@ def test_conv3d_f16_winograd_depth_form(hc, N, D, Hh, W, ci, co):
     (6, 1, 4, 16, 16, 64, 128),       # Winograd-D form
     (6, 2, 5, 8, 24, 32, 256),        # odd D, batch 2, two cout blocks
     (6, 1, 64, 8, 8, 256, 384),       # Winograd-D + split-K
+    (6, 1, 64, 4, 4, 512, 384),       # Winograd-D on 4x4x8 tiles + split-K
+    (6, 2, 9, 4, 7, 32, 128),         # 4x4x8 tiles, ragged
 ])
 def test_conv3d_bf16_mode(hc, precision, N, D, Hh, W, ci, co):
     """precisions 5 / 6: one bf16 MFMA per product on bf16-rounded operands (8 significant bits), fp32

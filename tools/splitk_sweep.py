@@ -26,6 +26,9 @@ SHAPES = [  # (Cin, Cout, D, H, W) of the published network's split levels (SURV
     (512, 128, 64, 16, 16), (256, 128, 64, 16, 16),
     (256, 256, 64, 8, 8), (256, 384, 64, 8, 8), (384, 384, 64, 8, 8), (768, 384, 64, 8, 8), (768, 256, 64, 8, 8),
     (512, 256, 64, 8, 8),
+    # the 64x4x4 level (4x4x8 tiles since r03)
+    (384, 384, 64, 4, 4), (384, 512, 64, 4, 4), (512, 512, 64, 4, 4), (1024, 512, 64, 4, 4), (1024, 384, 64, 4, 4),
+    (768, 384, 64, 4, 4),
 ]
 SHAPES_1X1 = [  # the skip connections (unet.py:173-186) of the published network
     (256, 128, 64, 64, 64), (256, 128, 64, 32, 32),
@@ -33,7 +36,7 @@ SHAPES_1X1 = [  # the skip connections (unet.py:173-186) of the published networ
     (256, 384, 64, 8, 8), (768, 384, 64, 8, 8), (768, 256, 64, 8, 8), (512, 256, 64, 8, 8),
     (384, 512, 64, 4, 4), (1024, 512, 64, 4, 4), (1024, 384, 64, 4, 4), (768, 384, 64, 4, 4),
 ]
-SPLITS = [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24]
+SPLITS = [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32]
 
 
 def main():
