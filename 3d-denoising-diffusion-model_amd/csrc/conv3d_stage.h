@@ -182,8 +182,12 @@ __device__ __forceinline__ void stage_write(const StageLaneT<G>& s, const StageR
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float ys = __builtin_fmaf(x[c], sa[c], sb[c]);
+#ifdef DDPM3D_WZ_NOSILU   // measurement only (wrong results): what the two transcendentals per value cost
+                    d[c] = ys;
+#else
                     const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(ys, s.km, s.ka));
                     d[c] = ys * __builtin_amdgcn_rcpf(1.0f + e);
+#endif
                 }
             } else {
 #pragma unroll
