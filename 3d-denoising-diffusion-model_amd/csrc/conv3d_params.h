@@ -71,7 +71,11 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
     c.PREC = 0;  // set by the caller from the descriptor
     c.KS = ksize;
     c.WN = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
+#ifdef DDPM3D_FORCE_T4_3X3   // measurement only: 4x4x8 tiles for every 3x3x3 layer (r03: slower)
+    if (H >= 8 && W >= 8 && ksize != 3) { c.TXL = 3; c.TYL = 3; } else { c.TXL = 2; c.TYL = 2; }
+#else
     if (H >= 8 && W >= 8) { c.TXL = 3; c.TYL = 3; } else { c.TXL = 2; c.TYL = 2; }
+#endif
     c.MT = c.WN;  // 128-voxel tile (a 256-voxel tile, 8 accumulators per wave, measured 2.2x slower: r01)
     const int TX = 1 << c.TXL, TY = 1 << c.TYL, TZ = (4 / c.WN) * c.MT * 32 / (TX * TY);
     c.tilesX = (W + TX - 1) / TX;
