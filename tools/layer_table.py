@@ -64,6 +64,10 @@ def main():
         tag, fl = plan.conv_meta[i]
         fn, args = plan.steps[i]
         tot += ms[j]
+        if tag == "pool_act":                                  # ddpm3d_pool_act(src, A, B, act, fast, N, D, H, W, C, ...)
+            print("%3d  %-24s %-6s %-12s %-14s %2s  %8.3f %8s" % (j, tag, "pool", "%d" % args[9], "%dx%dx%d" % (args[6], args[7], args[8]),
+                                                                  "-", ms[j], "-"))
+            continue
         if tag.startswith("attention"):
             print("%3d  %-24s %-6s %-12s %-14s %2s  %8.3f %8.1f" % (j, tag, "-", "-", "T=%d" % args[2], "-", ms[j], fl / ms[j] / 1e9))
             continue
