@@ -181,6 +181,77 @@ def test_full_size_winograd_kernel_vs_cpu_conv(ci, upsampled):
     check_stats(stats, ref)
 
 
+@pytest.mark.parametrize("precision,dims", [(1, (64, 32, 32)), (5, (64, 64, 64)), (1, (64, 64, 64))])
+def test_full_size_skip_connection_conv_vs_cpu(precision, dims):
+    """The decoder's 1x1 skip conv at its published shapes -- virtual concat 128 + 128 -> 128 -- against
+    F.conv3d on the CPU: the register-fed kernel (conv1x1.hip) at 64x32x32 in the default arithmetic and at
+    64^3 in the bf16 mode (2048 workgroups, bf16 tensors), and the 64^3 layer in the default arithmetic, which
+    the library routes to the general kernel (> 1024 workgroups).  Residual accumulated in place, as the
+    engine does (the conv2 of the block adds onto the skip result)."""
+    import hipcall as hc
+    import guided_diffusion._hip as H
+    from test_gpu_ops import rnd
+    D, Hh, W = dims
+    half = precision == 5
+    x = rnd(1, 256, D, Hh, W, seed=11) * 2.0
+    w = rnd(128, 256, 1, 1, 1, seed=12, scale=0.05)
+    b = rnd(128, seed=13)
+    xs = x.bfloat16() if half else x
+    torch.set_num_threads(16)
+    if half:
+        ref = F.conv3d(xs.float().double(), w.bfloat16().double(), b.double()).float()
+    else:
+        ref = F.conv3d(x.double(), w.double(), b.double()).float()
+    xd = hc.to_ndhwc(xs).cuda()
+    srcs = [xd[..., :128].contiguous(), xd[..., 128:].contiguous()]
+    out, _, _ = hc.conv3d(srcs, w.cuda(), b.cuda(), (D, Hh, W), precision=precision, want_stats=False)
+    got = hc.to_ncdhw(out.float().cpu())
+    assert rel_err_per_channel(got.numpy(), ref.numpy()) < (1e-5 if half else 3e-6)
+
+
+def test_full_size_down_block_prepass_and_small_level_winograd():
+    """Two r03 paths at the published shapes.  (1) ddpm3d_pool_act on the 64^3 -> 64x32x32 down ResBlock's input
+    (GroupNorm-style affine + SiLU + AvgPool3d((1,2,2))) followed by the Winograd-D conv on the plain pooled
+    tensor, against avg_pool3d + conv3d on the CPU.  (2) 512 -> 512 @ 64x4x4: the Winograd-D form on 4x4x8
+    tiles with its 16-way split over Cin, residual and statistics, against F.conv3d."""
+    import hipcall as hc
+    import guided_diffusion._hip as H
+    from test_gpu_ops import TOL, check_stats, rnd
+    lib = H.load()
+    torch.set_num_threads(16)
+    D, Hh, W, Cn = 64, 32, 32, 128
+    x = rnd(1, Cn, D, 2 * Hh, 2 * W, seed=21)
+    a = 1.0 + 0.1 * rnd(1, Cn, seed=22)
+    bb = 0.1 * rnd(1, Cn, seed=23)
+    w = rnd(128, Cn, 3, 3, 3, seed=24, scale=0.03)
+    b = rnd(128, seed=25)
+    pooled_ref = F.avg_pool3d(F.silu(x * a[:, :, None, None, None] + bb[:, :, None, None, None]), (1, 2, 2))
+    ref = F.conv3d(pooled_ref, w, b, padding=1)
+    xd = hc.to_ndhwc(x).cuda()
+    pooled = torch.empty(1, D, Hh, W, Cn, dtype=torch.float32, device="cuda")
+    ad, bd = a.cuda(), bb.cuda()
+    H.check(lib.ddpm3d_pool_act(H.ptr(xd), H.ptr(ad), H.ptr(bd), H.ACT_SILU, 1, 1, D, Hh, W, Cn, H.ptr(pooled), 0,
+                                H.stream()))
+    torch.cuda.synchronize()
+    assert rel_err(hc.to_ncdhw(pooled.cpu()).numpy(), pooled_ref.numpy()) < 2e-6
+    bound = pooled_ref.abs().amax().reshape(1, 1).cuda()
+    out, stats, _ = hc.conv3d([pooled], w.cuda(), b.cuda(), (D, Hh, W), precision=3, bound=bound)
+    assert rel_err_per_channel(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)
+    # (2)
+    x4 = rnd(1, 512, 64, 4, 4, seed=31)
+    w4 = rnd(512, 512, 3, 3, 3, seed=32, scale=0.02)
+    b4 = rnd(512, seed=33)
+    a4 = 1.0 + 0.1 * rnd(1, 512, seed=34)
+    bb4 = 0.1 * rnd(1, 512, seed=35)
+    r4 = rnd(1, 512, 64, 4, 4, seed=36)
+    ref4 = F.conv3d(F.silu(x4 * a4[:, :, None, None, None] + bb4[:, :, None, None, None]), w4, b4, padding=1) + r4
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(x4).cuda()], w4.cuda(), b4.cuda(), (64, 4, 4), aff=(a4.cuda(), bb4.cuda()),
+                              act=H.ACT_SILU, res=hc.to_ndhwc(r4).cuda(), res_mode=H.RES_SAME, precision=3)
+    assert rel_err_per_channel(hc.to_ncdhw(out.cpu()).numpy(), ref4.numpy()) < TOL
+    check_stats(stats, ref4)
+
+
 def test_script_patch_shape_96_cubed():
     """The shape the reference's launcher really runs (test_DDPM_3d_mpi.sh / README.md: --large_size 96,
     patches of 96^3, published architecture): resolutions 96 / 48 / 24 / 12 / 6, i.e. tile grids that
