@@ -306,33 +306,45 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(
     }
 }
 
-// max |x| per sample of up to two tensors: bound[n * count + t]
-__global__ __launch_bounds__(1024) void absmax_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
-                                                      size_t per_sample, int count, float* __restrict__ bound) {
-    const int n = blockIdx.x / count, t = blockIdx.x % count;
+// max |x| per sample of up to two tensors: bound[n * count + t].  ABSMAX_PARTS workgroups per (sample, tensor)
+// fold their slices with an atomic max on the bit patterns (non-negative floats order like unsigned integers:
+// exact, so the result does not depend on arrival order); the launcher zeroes `bound` first.  (r03: ONE
+// 1024-thread workgroup per tensor walked its 1 MB in a 64-deep dependent loop: 36 us per DDPM step.)
+#define ABSMAX_PARTS 32
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                     size_t per_sample, int count, float* __restrict__ bound) {
+    const int part = blockIdx.x % ABSMAX_PARTS, nt = blockIdx.x / ABSMAX_PARTS;
+    const int n = nt / count, t = nt % count;
     const float* x = (t == 0 ? x0 : x1) + (size_t)n * per_sample;
     float m = 0.0f;
     const size_t quads = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? per_sample / 4 : 0;
-    for (size_t i = threadIdx.x; i < quads; i += blockDim.x) {
+    const size_t qper = (quads + ABSMAX_PARTS - 1) / ABSMAX_PARTS;
+    const size_t q0 = (size_t)part * qper, q1 = q0 + qper < quads ? q0 + qper : quads;
+#pragma unroll 4
+    for (size_t i = q0 + threadIdx.x; i < q1; i += 256) {
         const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
-    for (size_t i = quads * 4 + threadIdx.x; i < per_sample; i += blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    if (part == 0)   // the unaligned / remainder elements
+        for (size_t i = quads * 4 + threadIdx.x; i < per_sample; i += 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    __shared__ float red[16];
+    __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
-        bound[blockIdx.x] = m;
+        for (int w = 1; w < 4; ++w) m = fmaxf(m, red[w]);
+        // m is a non-negative, non-NaN float (fmaxf drops NaNs): its bits order like the value
+        atomicMax(reinterpret_cast<unsigned*>(bound) + nt, __float_as_uint(m));
     }
 }
 
 hipError_t ddpm3d_launch_absmax(const float* x0, const float* x1, int N, size_t per_sample, float* bound,
                                 hipStream_t st) {
     const int count = x1 ? 2 : 1;
-    hipLaunchKernelGGL(absmax_kernel, dim3(N * count), dim3(1024), 0, st, x0, x1, per_sample, count, bound);
+    hipError_t e = hipMemsetAsync(bound, 0, sizeof(float) * (size_t)N * count, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(absmax_kernel, dim3(N * count * ABSMAX_PARTS), dim3(256), 0, st, x0, x1, per_sample, count, bound);
     return hipGetLastError();
 }
 

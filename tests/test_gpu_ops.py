@@ -903,3 +903,30 @@ def test_pool_act_prepass(hc, store):
     # rejected: C not a multiple of 4, an activation without the affine
     assert lib.ddpm3d_pool_act(H.ptr(xs), 0, 0, H.ACT_NONE, 0, N, D, Hh, W, 30, H.ptr(out), io_in, H.stream()) == H.E_INVAL
     assert lib.ddpm3d_pool_act(H.ptr(xs), 0, 0, H.ACT_SILU, 0, N, D, Hh, W, Cn, H.ptr(out), io_in, H.stream()) == H.E_INVAL
+
+
+def test_absmax_is_exact_and_order_free(hc):
+    """ddpm3d_absmax (the range bound of tensors no conv epilogue produced: the network's two input volumes):
+    max |x| per sample and tensor, exactly, from 32 workgroups per tensor folded by an atomic max on the bit
+    patterns -- including sizes that are not a multiple of the vector width or of the workgroup slices, an
+    unaligned base pointer, and a sample whose maximum sits in the last element."""
+    import guided_diffusion._hip as H
+    lib = H.load()
+    for N, per in ((1, 64 ** 3), (3, 40 * 33 * 17), (2, 5), (2, 4099)):
+        g = torch.Generator().manual_seed(per)
+        a = (torch.randn(N, per, generator=g) * 3).cuda()
+        b = (torch.randn(N, per + 1, generator=g) * 0.01).cuda()[:, 1:].contiguous()
+        a[-1, -1] = -1234.5
+        bound = torch.full((N, 2), float("nan"), device="cuda")
+        for _ in range(2):      # a second call must not see the first one's result
+            H.check(lib.ddpm3d_absmax(H.ptr(a), H.ptr(b), N, per, H.ptr(bound), H.stream()))
+        torch.cuda.synchronize()
+        want = torch.stack([a.abs().amax(dim=1), b.abs().amax(dim=1)], dim=1)
+        assert torch.equal(bound, want)
+        # one tensor, unaligned base (the scalar path)
+        flat = torch.randn(N * per + 1, generator=g).cuda()
+        u = flat[1:]
+        b1 = torch.full((N,), float("nan"), device="cuda")
+        H.check(lib.ddpm3d_absmax(H.ptr(u), 0, N, per, H.ptr(b1), H.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(b1, u.reshape(N, per).abs().amax(dim=1))
