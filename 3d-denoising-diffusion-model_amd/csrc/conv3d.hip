@@ -516,6 +516,25 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
             hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 4, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds4, st, k);
         return hipGetLastError();
     }
+#ifndef DDPM3D_WZ_T84
+#define DDPM3D_WZ_T84 1
+#endif
+    // 8x4x4 tiles (two z-pairs per workgroup; r03) where they tile the volume like the 8x8x2 grid the shape rule
+    // counted (H % 8 == 0, D % 4 == 0: same number of tiles, so statistics rows and workspace are unchanged); the
+    // default issue order only
+    if (DDPM3D_WZ_T84 && k.H % 8 == 0 && k.D % 4 == 0 && !(k.hint & DDPM3D_HINT_WZ_ORDER_MASK)) {
+        ConvK k2 = k;
+        k2.tilesY = 2 * k.tilesY;
+        k2.tilesZ = k.tilesZ / 2;
+        constexpr size_t lds84 = (size_t)WzGeomT<8, 4>::BUF;
+        if (c.PREC == DDPM3D_PREC_F16_WZ)
+            hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16, 0, 8, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds84, st, k2);
+        else if (c.PREC == DDPM3D_PREC_BF16_WZ)
+            hipLaunchKernelGGL((conv3d_wz_kernel<WZ_BF16, 0, 8, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds84, st, k2);
+        else
+            hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16X3, 4, 8, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds84, st, k2);
+        return hipGetLastError();
+    }
     if (c.PREC == DDPM3D_PREC_F16_WZ)
         hipLaunchKernelGGL(conv3d_wz_kernel<WZ_F16>, dim3(gx, gy, k.ksplit), dim3(256), lds, st, k);
     else if (c.PREC == DDPM3D_PREC_BF16_WZ)

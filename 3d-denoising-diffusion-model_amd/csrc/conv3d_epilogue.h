@@ -59,12 +59,12 @@ __device__ __forceinline__ void quad_transpose(float (&a)[4], bool b0, bool b1) 
 // row = (reg&3) + 8*(reg>>2) + 4*half.
 // inv_act = 1 / activation scale of this sample (split-f16 modes; 1 in the exact mode)
 // WIDE: the 16-byte store form below (one-MFMA modes), or the four-byte form
-// ZPAIRS (conv3d_wz.h on 4x4x8 tiles): accumulator u = zbit*2 + t holds, in its rows 0-15 / 16-31, output plane
-// zbit of the z-pairs 2t / 2t+1 -- depth 4t + 2 (row >> 4) + zbit instead of the plain 2u + (row >> 4)
+// ZPAIRS (conv3d_wz.h on tiles of several z-pairs, RP = TX * TY positions each): accumulator u = zbit*2 + t holds, in
+// row r, output plane zbit of z-pair (t*32 + r) / RP -- depth 2 * pair + zbit instead of the plain m / RP
 template <int TXL, int TYL, bool ZPAIRS>
 __device__ __forceinline__ constexpr int epi_tz(int m) {
-    const int r = m >> (TXL + TYL);
-    return ZPAIRS ? 4 * ((r >> 1) & 1) + 2 * (r & 1) + (r >> 2) : r;
+    const int u = m >> 5, r = m & 31;
+    return ZPAIRS ? 2 * ((((u & 1) << 5) + r) >> (TXL + TYL)) + (u >> 1) : m >> (TXL + TYL);
 }
 
 template <int PREC, int WM, int MT, int TXL, int TYL, bool WIDE = false, bool ZPAIRS = false>

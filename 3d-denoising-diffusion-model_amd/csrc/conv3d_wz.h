@@ -42,15 +42,15 @@
 #define WZ_STAMP(i) do { } while (0)
 #endif
 
-// TXY = 8: 8x8x2 tiles (H, W >= 8).  TXY = 4 (r03): 4x4x8 tiles = four z-pairs of 16 (y, x) positions, for the
-// 64x4x4 level, which the direct kernel's 4x4 tiles ran at 1.5x the MFMAs (conv3d_stage.h WzGeomT); a 32-row
-// MFMA tile is then two z-pairs' worth of one transformed plane, the tap loop below is the same code.
-template <int MODE, int IL = 0, int TXY = 8>
+// Tile forms (conv3d_stage.h WzGeomT): 8 x 8 x 2 (one z-pair), 8 x 4 x 4 (two; r03), 4 x 4 x 8 (four: the levels
+// below 8x8, which the direct kernel's 4x4 tiles ran at 1.5x the MFMAs; r03).  A 32-row MFMA tile is 32 positions of
+// one transformed plane -- half a pair, one pair or two pairs' worth; the tap loop below is the same code for all.
+template <int MODE, int IL = 0, int TX = 8, int TY = TX>
 __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
-    typedef WzGeomT<TXY> G;
+    typedef WzGeomT<TX, TY> G;
     constexpr bool X3 = MODE == WZ_F16X3;
     constexpr int CK = DDPM3D_CONV_CK, NT = 36;
-    constexpr int TX = TXY, TXL = TXY == 8 ? 3 : 2, TYL = TXL;
+    constexpr int TXL = TX == 8 ? 3 : 2, TYL = TY == 8 ? 3 : 2;
     constexpr int VS = G::VS, RY = G::RY, RZ = G::RZ;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -70,18 +70,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     const int ty_i = tile % p.tilesY; tile /= p.tilesY;
     const int tz_i = tile % p.tilesZ; tile /= p.tilesZ;
     const int n = tile;
-    const int x0 = tx_i * TX, y0 = ty_i * TX, z0 = tz_i * 2 * G::NZP;
+    const int x0 = tx_i * TX, y0 = ty_i * TY, z0 = tz_i * 2 * G::NZP;
 
-    // GEMM rows of this wave, two 32-row MFMA tiles: the 64 (y, x) positions of the 8x8 tile, or the 16
-    // positions of the 4x4 tile in each of its four z-pairs (row m: pair m >> 4)
+    // GEMM rows of this wave, two 32-row MFMA tiles: row m = position m % RP of z-pair m / RP
     int arow[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int m = t * 32 + (lane & 31);
-        if constexpr (TXY == 8)
-            arow[t] = ((m >> TXL) * RY + (m & (TX - 1)) * VS + half) * 16;
-        else
-            arow[t] = (m >> 4) * G::PAIR + (((m >> TXL) & (TX - 1)) * RY + (m & (TX - 1)) * VS + half) * 16;
+        const int pos = m % G::RP;
+        arow[t] = (m / G::RP) * G::PAIR + ((pos >> TXL) * RY + (pos & (TX - 1)) * VS + half) * 16;
     }
 
     const int cout = wg.cy * 128 + wn * 32 + (lane & 31);
@@ -230,8 +227,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     WZ_STAMP(42);
 
     // ---- output transform (register-local), then the common epilogue on the tile:
-    // virtual accumulator u = zbit*2 + t covers rows m = u*32 + row -> 8x8x2: (tz = zbit, ty, tx); 4x4x8: the
-    // two z-pairs 2t and 2t+1 of row tile t, i.e. tz = 4t + 2 (row >> 4) + zbit (conv_epilogue's ZPAIRS map)
+    // virtual accumulator u = zbit*2 + t covers rows m = u*32 + row: output plane zbit of z-pair (t*32 + row) / RP,
+    // i.e. depth 2 * pair + zbit (conv_epilogue's ZPAIRS map; for 8x8x2 that is the plain tz = zbit)
     f32x16 outv[4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -239,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         outv[2 + t] = acc[1][t] - acc[2][t] - acc[3][t];
     }
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<1, 1, 4, TXL, TYL, MODE != WZ_F16X3, TXY == 4>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split,
+    conv_epilogue<1, 1, 4, TXL, TYL, MODE != WZ_F16X3, G::NZP != 1>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split,
                                                                  asc.inv, true, pre_ws, pre_bias);
 #ifdef DDPM3D_WZ_STAMPS
     WZ_STAMP(43);

@@ -110,6 +110,8 @@ def test_conv3d_f16x3_accuracy_is_fp32_grade(hc):
     (2, 5, 8, 24, 32, 256),      # odd D (last z-pair half valid), batch 2, two cout blocks
     (1, 1, 9, 12, 16, 128),      # D = 1, ragged H / W
     (1, 64, 8, 8, 256, 384),     # the published net's 8x8 level: split-K + reduce kernel
+    (1, 8, 8, 12, 32, 128),      # 8x4x4 tiles (H % 8 == 0, D % 4 == 0: two z-pairs per tile), ragged W
+    (2, 4, 24, 16, 16, 256),     # 8x4x4 tiles, batch 2, six tile rows
     (1, 64, 4, 4, 512, 512),     # its 4x4 level: 4x4x8 tiles (four z-pairs per tile), split-K + reduce
     (2, 5, 4, 6, 32, 128),       # 4x4x8 tiles, ragged in all three extents (D = 5: pairs 2, 3 of the tile empty / half)
     (1, 11, 7, 3, 16, 256),      # W < 4, D not a multiple of 8, two cout blocks
@@ -147,6 +149,20 @@ def test_conv3d_winograd_depth_exact_and_fused_paths(hc):
     ref = F.conv3d(up(F.silu(F.group_norm(xc, 32, gamma, beta, 1e-5))), w2, b2, padding=1) + up(r)
     A, B = _gn_affine(hc, [xa, xb], gamma, beta)
     out, stats, _ = hc.conv3d([hc.to_ndhwc(xa).cuda(), hc.to_ndhwc(xb).cuda()], w2.cuda(), b2.cuda(), (3, 8, 12),
+                              in_mode=H.IN_UP, aff=(A, B), act=H.ACT_SILU, res=hc.to_ndhwc(r).cuda(),
+                              res_mode=H.RES_UP, precision=3)
+    assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
+    check_stats(stats, ref)
+    # the same on 8x4x4 tiles (H % 8 == 0, D % 4 == 0; r03): exact integers, up-sampled block path with a concat
+    x8 = torch.from_numpy(g.integers(-3, 4, (1, 16, 8, 8, 10)).astype(np.float32))
+    out, _, _ = hc.conv3d([hc.to_ndhwc(x8).cuda()], w.cuda(), b.cuda(), (8, 8, 10), precision=3)
+    assert torch.equal(hc.to_ncdhw(out.cpu()), F.conv3d(x8, w, b, padding=1))
+    xa, xb = rnd(1, 32, 4, 4, 6, seed=21), rnd(1, 32, 4, 4, 6, seed=22)
+    xc = torch.cat([xa, xb], 1)
+    r = rnd(1, 128, 4, 4, 6, seed=28)
+    ref = F.conv3d(up(F.silu(F.group_norm(xc, 32, gamma, beta, 1e-5))), w2, b2, padding=1) + up(r)
+    A, B = _gn_affine(hc, [xa, xb], gamma, beta)
+    out, stats, _ = hc.conv3d([hc.to_ndhwc(xa).cuda(), hc.to_ndhwc(xb).cuda()], w2.cuda(), b2.cuda(), (4, 8, 12),
                               in_mode=H.IN_UP, aff=(A, B), act=H.ACT_SILU, res=hc.to_ndhwc(r).cuda(),
                               res_mode=H.RES_UP, precision=3)
     assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < TOL
