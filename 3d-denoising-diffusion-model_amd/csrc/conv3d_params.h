@@ -103,7 +103,10 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
     if (ksize == 3 && c.WN == 4) {
         static const double eff[4] = {1.0, 0.62, 0.78, 0.82};
         double best_cost = 1e300;
-        for (int s = 1; s <= 32 && s <= nch; ++s) {
+        // (at most 16 ways: the model does not price the reduce kernel's S slab reads; the one shape it sent
+        // to 32 -- 1024 -> 384 @ 64x4x4 -- is 11 % / 23 % faster at 16 in the f16x3 / bf16 forms,
+        // profiles/r03_splitk_sweep_with_4x4x8.txt, r03_splitk_sweep_bf16.txt)
+        for (int s = 1; s <= 16 && s <= nch; ++s) {
             const int cps = (nch + s - 1) / s;
             if (s > 1 && cps < 2) break;
             const long long per_cu = (blocks * s + 255) / 256;
