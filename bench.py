@@ -53,6 +53,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+TRAFFIC_EPOCH = "wz8x4x4"   # see roofline.traffic_signature
 PUBLISHED = dict(large_size=96, small_size=96, num_channels=128, num_res_blocks=2, num_head_channels=64,
                  attention_resolutions="1000", learn_sigma=True, resblock_updown=True,
                  use_scale_shift_norm=True)
@@ -391,7 +392,9 @@ def main():
         # pass over THIS workload (tools/pmc_bench.sh -> profiles/rNN_pmc_traffic.json);
         # null for any other configuration.
         traffic, traffic_src = None, None
-        sig = "%s|%d|%d|%s|%s" % (args.precision, S, B, args.arch, args.attention_resolutions)
+        # (the last field names the dominant kernel's tile form: bump it with any change to that kernel's memory
+        # behaviour, so that a traffic file measured on an older form stops matching instead of going stale)
+        sig = "%s|%d|%d|%s|%s|%s" % (args.precision, S, B, args.arch, args.attention_resolutions, TRAFFIC_EPOCH)
         here = os.path.dirname(os.path.abspath(__file__))
         for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
             with open(f) as fh:

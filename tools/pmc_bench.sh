@@ -21,9 +21,10 @@ out = sys.argv[1]
 
 def bench_name(k):
     """rocprof kernel name -> the name bench.py reports for that launch"""
-    m = re.search(r"conv3d_wz_kernel<(\d+)", k)
-    if m:   # Winograd-D form of the f16x3 / f16 / bf16 arithmetic = precisions 3 / 4 / 6
-        return "conv3d_p%d_k3_wn4_t8" % {0: 3, 1: 4, 2: 6}[int(m.group(1))]
+    m = re.search(r"conv3d_wz_kernel<(\d+), (\d+), (\d+)", k)
+    if m:   # Winograd-D form of the f16x3 / f16 / bf16 arithmetic = precisions 3 / 4 / 6; <MODE, IL, TX, TY>: the
+            # engine's family tag says t8 for the 8-wide tiles (8x8x2, 8x4x4) and t4 for 4x4x8
+        return "conv3d_p%d_k3_wn4_t%d" % ({0: 3, 1: 4, 2: 6}[int(m.group(1))], int(m.group(3)))
     m = re.search(r"conv3d_skinny_kernel<(\d+)", k)
     if m:
         return "conv3d_p%d_k3_skinny" % {0: 1, 1: 2, 2: 5}[int(m.group(1))]
