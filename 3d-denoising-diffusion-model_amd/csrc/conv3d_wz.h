@@ -1,6 +1,7 @@
 // 3x3x3 convolution with Winograd F(2,3) along the DEPTH axis, split-f16 arithmetic
-// (DDPM3D_PREC_F16X3_WZ), for the layers that carry the network's FLOPs: 8x8x2 tiles,
-// 128-cout workgroups with every wave active, pipelined inputs (IN_SAME / IN_UP).
+// (DDPM3D_PREC_F16X3_WZ), for the layers that carry the network's FLOPs: 128-voxel tiles of one, two
+// or four z-pairs (8x8x2, 8x4x4, 4x4x8: conv3d_stage.h WzGeomT), 128-cout workgroups with every wave
+// active, pipelined inputs (IN_SAME / IN_UP).
 //
 // For one output pair (z, z+1) at a fixed (y, x) and one (dy, dx):
 //     V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3        (d_k = input plane z-1+k)
@@ -10,11 +11,11 @@
 // i.e. 4 products per two outputs instead of 6: 36 "taps" (j, dy, dx) per 16-channel chunk
 // feeding four accumulator sets, 216 MFMAs per wave and chunk instead of 324.
 //
-// Why depth: D is never strided in this network (unet.py:129), the workgroup tile is 8x8x2
-// = exactly ONE z-pair per (y, x), and that pair's four halo planes are exactly the
-// transform's four inputs -- so the transformed image V has the SAME LDS footprint as the
-// plain halo image (4 planes of 10x10 voxels) and a tap is, as before, a compile-time LDS
-// offset (plane j instead of plane dz).  The input transform is done in fp32 on the
+// Why depth: D is never strided in this network (unet.py:129), the workgroup tile is whole
+// z-pairs per (y, x), and a pair's four halo planes are exactly the transform's four inputs --
+// so the transformed image V of a pair has the SAME LDS footprint as its plain halo image (4
+// planes) and a tap is, as before, a compile-time LDS offset (plane j instead of plane dz).
+// Consecutive pairs of a tile share two input planes (two new planes per pair).  The input transform is done in fp32 on the
 // normalised+activated values while staging (before the f16 hi/lo split); the weight
 // transform at pack time (ops.hip); the output transform is register-local in the epilogue
 // (the four M_j of an output live in the same lane and register index).
