@@ -237,7 +237,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         outv[2 + t] = acc[1][t] - acc[2][t] - acc[3][t];
     }
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    conv_epilogue<1, 1, 4, TXL, TYL, MODE != WZ_F16X3, G::NZP != 1>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split,
+    #ifndef DDPM3D_WZ_WIDE_X3
+#define DDPM3D_WZ_WIDE_X3 0     // measurement: the 16-byte epilogue in the f16x3 form too
+#endif
+    conv_epilogue<1, 1, 4, TXL, TYL, MODE != WZ_F16X3 || DDPM3D_WZ_WIDE_X3, G::NZP != 1>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split,
                                                                  asc.inv, true, pre_ws, pre_bias);
 #ifdef DDPM3D_WZ_STAMPS
     WZ_STAMP(43);
