@@ -64,6 +64,34 @@ def test_library_exports_every_declared_symbol():
     assert ws > 0 and ws % (1024 * 512 * 4) == 0
 
 
+def test_split_rule_and_prepass_argument_checks_without_a_gpu():
+    """Host-side rules a caller sizes buffers by (no kernel is launched): the split over Cin stays within 16
+    ways for 3x3x3 convs (r03: the reduce kernel's S slab reads are not in the cost model) and within the
+    chunk count for 1x1 convs, the workspace is S whole output tensors; ddpm3d_pool_act refuses channel counts
+    that are not a multiple of 4 and an activation without its affine before it touches the device."""
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    lib.ddpm3d_conv_workspace_bytes.restype = ctypes.c_size_t
+    for (D, H, W, ci, co, k) in [(64, 4, 4, 1024, 384, 3), (64, 4, 4, 512, 512, 3), (64, 8, 8, 768, 384, 3),
+                                 (64, 4, 4, 1024, 512, 1), (64, 8, 8, 768, 384, 1), (64, 16, 16, 512, 256, 1)]:
+        out_bytes = D * H * W * co * 4
+        ws = lib.ddpm3d_conv_workspace_bytes(1, D, H, W, ci, co, k)
+        assert ws % out_bytes == 0
+        S = ws // out_bytes
+        assert S <= (16 if k == 3 else ci // 16), (D, H, W, ci, co, k, S)
+    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 1024, 384, 3) == 16 * 64 * 4 * 4 * 384 * 4
+    lib.ddpm3d_pool_act.restype = ctypes.c_int
+    vp = ctypes.c_void_p
+    lib.ddpm3d_pool_act.argtypes = [vp, vp, vp] + [ctypes.c_int] * 7 + [vp, ctypes.c_int, vp]
+    buf = (ctypes.c_float * 64)()
+    a = ctypes.addressof(buf)
+    a16 = (a + 15) & ~15
+    assert lib.ddpm3d_pool_act(a16, None, None, 0, 0, 1, 1, 1, 1, 6, a16, 0, None) == _hip.E_INVAL     # C % 4
+    assert lib.ddpm3d_pool_act(a16, None, None, 1, 0, 1, 1, 1, 1, 4, a16, 0, None) == _hip.E_INVAL     # act without affine
+    assert lib.ddpm3d_pool_act(a16, a16, None, 0, 0, 1, 1, 1, 1, 4, a16, 0, None) == _hip.E_INVAL      # A without B
+    assert lib.ddpm3d_pool_act(a16, None, None, 0, 0, 1, 1, 1, 1, 4, a16, 0x40, None) == _hip.E_INVAL  # unknown io bits
+    assert lib.ddpm3d_pool_act(None, None, None, 0, 0, 1, 1, 1, 1, 4, a16, 0, None) == _hip.E_INVAL    # null source
+
+
 def test_conv_desc_struct_layout_matches_header():
     """Field order/offsets of the ctypes mirror: 8 ints, 2 ptrs, 2 ints, 2 ptrs, 2 ints, ..."""
     f = {n: getattr(_hip.ConvDesc, n).offset for n, _ in _hip.ConvDesc._fields_}
