@@ -57,17 +57,20 @@ int ddpm3d_pack_conv_weight(const float* w, int Cout, int Cin, int ksize, int pr
                     "pack_conv_weight");
 }
 
-int ddpm3d_conv_stats_rows(int N, int D, int H, int W, int Cin, int Cout, int ksize) {
-    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    return ddpm3d_conv_cfg(N, D, H, W, Cin, Cout, ksize).stats_rows;
+int ddpm3d_conv_stats_rows(int N, int D, int H, int W, int Cin, int Cout, int ksize, int precision) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !prec_ok(precision)) return 0;
+    return ddpm3d_conv_cfg(N, D, H, W, Cin, Cout, ksize, precision).stats_rows;
 }
 
-size_t ddpm3d_conv_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int ksize) {
-    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-    return ddpm3d_conv_cfg(N, D, H, W, Cin, Cout, ksize).workspace_bytes;
+size_t ddpm3d_conv_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int ksize, int precision) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !prec_ok(precision)) return 0;
+    return ddpm3d_conv_cfg(N, D, H, W, Cin, Cout, ksize, precision).workspace_bytes;
 }
 
-int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
+// Validation and routing shared by ddpm3d_conv3d and ddpm3d_conv_kernel_family: fills the launch record and
+// says which kernel takes the call.
+enum { ROUTE_GENERAL = 0, ROUTE_SKINNY = 1, ROUTE_PW = 2 };
+static int conv_prepare(const ddpm3d_conv_desc* d, ConvK& k, ConvCfg& c, int& route, bool for_launch) {
     if (!d) return fail(DDPM3D_EINVAL, "conv3d: null descriptor");
     if (d->N <= 0 || d->D <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->Cin <= 0)
         return fail(DDPM3D_EINVAL, "conv3d: non-positive shape N=%d D=%d H=%d W=%d Cin=%d Cout=%d", d->N, d->D,
@@ -75,16 +78,17 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     if (d->ksize != 1 && d->ksize != 3) return fail(DDPM3D_EINVAL, "conv3d: ksize %d (1 or 3)", d->ksize);
     if (!prec_ok(d->precision)) return fail(DDPM3D_ENOSUP, "conv3d: precision mode %d not implemented", d->precision);
     if (d->C0 + d->C1 != d->Cin) return fail(DDPM3D_EINVAL, "conv3d: C0+C1 != Cin");
-    if (!d->src0 || !d->w_packed || !d->bias || !d->out) return fail(DDPM3D_EINVAL, "conv3d: null buffer");
+    // (a family query may come before the caller has attached its per-call buffers)
+    if (for_launch && (!d->src0 || !d->w_packed || !d->bias || !d->out)) return fail(DDPM3D_EINVAL, "conv3d: null buffer");
     if (d->in_mode == DDPM3D_IN_PLANAR2) {
-        if (d->Cin != 2 || d->C0 != 1 || d->C1 != 1 || !d->src1 || d->aff_a)
+        if (d->Cin != 2 || d->C0 != 1 || d->C1 != 1 || (for_launch && !d->src1) || d->aff_a)
             return fail(DDPM3D_EINVAL, "conv3d: planar2 input needs C0=C1=1, two planes, no affine");
     } else {
         if (d->in_mode < 0 || d->in_mode > DDPM3D_IN_STRIDE2) return fail(DDPM3D_EINVAL, "conv3d: in_mode %d", d->in_mode);
         if (d->in_mode == DDPM3D_IN_STRIDE2 && d->ksize != 3)
             return fail(DDPM3D_EINVAL, "conv3d: the strided input mode is the 3x3x3 Downsample conv's");
         if (d->Cin % DDPM3D_CONV_CK) return fail(DDPM3D_EINVAL, "conv3d: Cin=%d not a multiple of %d", d->Cin, DDPM3D_CONV_CK);
-        if (d->C1 > 0 && (d->C0 % DDPM3D_CONV_CK || !d->src1))
+        if (d->C1 > 0 && (d->C0 % DDPM3D_CONV_CK || (for_launch && !d->src1)))
             return fail(DDPM3D_EINVAL, "conv3d: concat needs C0 %% %d == 0 and src1", DDPM3D_CONV_CK);
         if (!aligned16(d->src0) || (d->src1 && !aligned16(d->src1)))
             return fail(DDPM3D_EINVAL, "conv3d: sources must be 16-byte aligned");
@@ -103,8 +107,7 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
     if (d->out_layout != DDPM3D_OUT_NDHWC && d->out_layout != DDPM3D_OUT_NCDHW)
         return fail(DDPM3D_EINVAL, "conv3d: out_layout %d", d->out_layout);
 
-    ConvCfg c = ddpm3d_conv_cfg(d->N, d->D, d->H, d->W, d->Cin, d->Cout, d->ksize);
-    c.PREC = d->precision;
+    c = ddpm3d_conv_cfg(d->N, d->D, d->H, d->W, d->Cin, d->Cout, d->ksize, d->precision);
     if (d->kernel_hint & DDPM3D_HINT_SPLITK_MASK) {
         // measurement only (tools/splitk_sweep.py): force the split factor; the caller sizes the workspace
         // for it and passes no statistics (their row count follows the library's own choice)
@@ -123,11 +126,10 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
           (d->in_mode == DDPM3D_IN_SAME || d->in_mode == DDPM3D_IN_UP)))
         return fail(DDPM3D_ENOSUP, "conv3d: the Winograd-D form needs ksize 3, Cout %% 128 == 0 "
                                    "and input mode SAME or UP; use the F16X3 packing for this call");
-    if (c.S > 1 && (!d->workspace || d->workspace_bytes < c.workspace_bytes || !aligned16(d->workspace)))
+    if (for_launch && c.S > 1 && (!d->workspace || d->workspace_bytes < c.workspace_bytes || !aligned16(d->workspace)))
         return fail(DDPM3D_EINVAL, "conv3d: this shape is split %d-way over Cin and needs %zu bytes of "
                                    "16-byte aligned workspace (got %zu)", c.S, c.workspace_bytes,
                     d->workspace ? d->workspace_bytes : (size_t)0);
-    ConvK k;
     memset(&k, 0, sizeof(k));
     k.src0 = d->src0; k.src1 = d->src1; k.affA = d->aff_a; k.affB = d->aff_b;
     k.w = (const float*)d->w_packed; k.bias = d->bias; k.res = d->res; k.out = d->out; k.stats = d->stats;
@@ -197,11 +199,40 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         d->res_mode == DDPM3D_RES_NONE &&
         ddpm3d_skinny_ok(k.CinPad, d->precision, !(d->io_dtype & DDPM3D_IO_SRC0_BF16) ? 0
                                                   : ((d->io_dtype & DDPM3D_IO_HALF_IS_F16) ? 2 : 1)))
+        route = ROUTE_SKINNY;
+    else
+        route = ddpm3d_pw_ok(k, c, d->ksize) ? ROUTE_PW : ROUTE_GENERAL;
+    return DDPM3D_OK;
+}
+
+int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
+    ConvK k;
+    ConvCfg c;
+    int route = ROUTE_GENERAL;
+    const int ok = conv_prepare(d, k, c, route, true);
+    if (ok != DDPM3D_OK) return ok;
+    if (route == ROUTE_SKINNY)
         return launched(ddpm3d_launch_conv_skinny(k, d->precision, (hipStream_t)stream), "conv3d (skinny)");
-    const int rc = ddpm3d_pw_ok(k, c, d->ksize) ? launched(ddpm3d_launch_conv_pw(k, c, (hipStream_t)stream), "conv3d (1x1)")
-                                                : launched(ddpm3d_launch_conv(k, c, (hipStream_t)stream), "conv3d");
+    const int rc = route == ROUTE_PW ? launched(ddpm3d_launch_conv_pw(k, c, (hipStream_t)stream), "conv3d (1x1)")
+                                     : launched(ddpm3d_launch_conv(k, c, (hipStream_t)stream), "conv3d");
     if (rc != DDPM3D_OK || c.S == 1) return rc;
     return launched(ddpm3d_launch_splitk_reduce(k, (hipStream_t)stream), "conv3d split-K reduce");
+}
+
+int ddpm3d_conv_kernel_family(const ddpm3d_conv_desc* d, char* name, int name_len) {
+    if (!name || name_len <= 0) return fail(DDPM3D_EINVAL, "conv_kernel_family: no buffer");
+    ConvK k;
+    ConvCfg c;
+    int route = ROUTE_GENERAL;
+    const int ok = conv_prepare(d, k, c, route, false);   // (the split-K workspace may be attached later)
+    if (ok != DDPM3D_OK) return ok;
+    const int tile = 1 << c.TXL;    // 8: 8x8x2 / 8x4x4 tiles, 4: 4x4x8
+    int n;
+    if (route == ROUTE_SKINNY) n = snprintf(name, (size_t)name_len, "conv3d_p%d_k3_skinny", d->precision);
+    else if (route == ROUTE_PW) n = snprintf(name, (size_t)name_len, "conv1x1_p%d_t%d", d->precision, tile);
+    else n = snprintf(name, (size_t)name_len, "conv3d_p%d_k%d_wn%d_t%d", d->precision, d->ksize, c.WN, tile);
+    if (n < 0 || n >= name_len) return fail(DDPM3D_EINVAL, "conv_kernel_family: buffer of %d bytes is too short", name_len);
+    return DDPM3D_OK;
 }
 
 int ddpm3d_gn_finalize(const double* stats0, int C0, int rows0, const double* stats1, int C1, int rows1,
@@ -275,7 +306,7 @@ int ddpm3d_add_embedding(float* emb, const float* table, const int64_t* idx, int
     if (!emb || !table || !idx || rows <= 0 || dim <= 0 || num_classes <= 0)
         return fail(DDPM3D_EINVAL, "add_embedding: bad arguments");
     (void)num_classes;   // the indices live on the device; the caller validates their range
-    return launched(ddpm3d_launch_add_embedding(emb, table, idx, rows, dim, (hipStream_t)stream), "add_embedding");
+    return launched(ddpm3d_launch_add_embedding(emb, table, idx, rows, dim, num_classes, (hipStream_t)stream), "add_embedding");
 }
 
 int ddpm3d_ncdhw_to_ndhwc(const float* in, int N, int C, int voxels, float* out, void* stream) {

@@ -487,10 +487,11 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     const int gy = k.CoutPad / 128;
     const int gx = k.N * k.tilesZ * k.tilesY * k.tilesX;
 #ifdef DDPM3D_WZ_STAMPS
-    constexpr size_t lds = (size_t)WzGeom::BUF + 4 * WZ_NSTAMP * 8;
+    constexpr size_t stamp_lds = 4 * WZ_NSTAMP * 8;     // measurement build: the stamps sit behind the image
 #else
-    constexpr size_t lds = (size_t)WzGeom::BUF;
+    constexpr size_t stamp_lds = 0;
 #endif
+    constexpr size_t lds = (size_t)WzGeom::BUF + stamp_lds;
     // One kernel form.  Measured and dropped in r02 (profiles/r02_layer_ab_*.txt, r02_wzp_plane_pair_*.txt,
     // DESIGN.md 3.1b): a wave-specialised persistent form (compute waves + loader waves, tile walk,
     // epilogue hand-off through LDS); a 128-row wave tile with one wave per SIMD (plain, and with the
@@ -507,7 +508,7 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
     // (profiles/r03_layer_ab_wz_issue_order.txt; r02 had picked between 0 and 1 by shape).
     if (c.TXL == 2) {
         // 4x4x8 tiles (the levels below 8x8: r03).  One issue order; the image is 56 KB
-        constexpr size_t lds4 = (size_t)WzGeomT<4>::BUF;
+        constexpr size_t lds4 = (size_t)WzGeomT<4>::BUF + stamp_lds;
         if (c.PREC == DDPM3D_PREC_F16_WZ)
             hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16, 0, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds4, st, k);
         else if (c.PREC == DDPM3D_PREC_BF16_WZ)
@@ -526,7 +527,7 @@ hipError_t ddpm3d_launch_conv_wz(const ConvK& k, const ConvCfg& c, hipStream_t s
         ConvK k2 = k;
         k2.tilesY = 2 * k.tilesY;
         k2.tilesZ = k.tilesZ / 2;
-        constexpr size_t lds84 = (size_t)WzGeomT<8, 4>::BUF;
+        constexpr size_t lds84 = (size_t)WzGeomT<8, 4>::BUF + stamp_lds;
         if (c.PREC == DDPM3D_PREC_F16_WZ)
             hipLaunchKernelGGL((conv3d_wz_kernel<WZ_F16, 0, 8, 4>), dim3(gx, gy, k.ksplit), dim3(256), lds84, st, k2);
         else if (c.PREC == DDPM3D_PREC_BF16_WZ)

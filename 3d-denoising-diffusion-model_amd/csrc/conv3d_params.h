@@ -66,9 +66,13 @@ static inline int ddpm3d_cin_pad(int Cin) { return ddpm3d_round_up(Cin, DDPM3D_C
 // to S workgroups per tile; the cost model below is (workgroups on the busiest
 // CU) x (chunks per workgroup + fixed cost) / (MFMA efficiency at that
 // co-residency), efficiencies measured on MI355X with the unsplit kernel.
-static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int Cout, int ksize) {
+// prec = DDPM3D_PREC_* of the call (ABI 12): the one-MFMA modes (f16, bf16) spend a third of the split-f16
+// modes' matrix time per chunk against the same fixed costs, so their split rule has constants of its own.
+static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int Cout, int ksize, int prec) {
     ConvCfg c;
-    c.PREC = 0;  // set by the caller from the descriptor
+    c.PREC = prec;
+    const bool one_mfma = prec == DDPM3D_PREC_F16 || prec == DDPM3D_PREC_F16_WZ || prec == DDPM3D_PREC_BF16 ||
+                          prec == DDPM3D_PREC_BF16_WZ;
     c.KS = ksize;
     c.WN = Cout > 64 ? 4 : (Cout > 32 ? 2 : 1);
 #ifdef DDPM3D_FORCE_T4_3X3   // measurement only: 4x4x8 tiles for every 3x3x3 layer (r03: slower)
@@ -100,13 +104,13 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
             if (cost < best_cost * 0.9) { best_cost = cost; best = s; }
         }
     }
-    if (ksize == 3 && c.WN == 4) {
+    if (ksize == 3 && c.WN == 4 && !one_mfma) {
         static const double eff[4] = {1.0, 0.62, 0.78, 0.82};
         double best_cost = 1e300;
         // (at most 16 ways, and a 1 % instead of a 3 % hysteresis: the model does not price the reduce kernel's
         // S slab reads; the one shape it sent to 32 -- 1024 -> 384 @ 64x4x4 -- is 11 % / 23 % faster at 16 in the
-        // f16x3 / bf16 forms.  Over the twenty shapes of profiles/r03_splitk_sweep_with_4x4x8.txt and
-        // r03_splitk_sweep_bf16.txt the rule's choices cost 1.693 / 0.911 ms, the best factor per cell 1.681 / 0.879.)
+        // f16x3 / bf16 forms.  Over the twenty shapes of profiles/r03_splitk_sweep_with_4x4x8.txt the rule's
+        // choices cost 1.693 ms, the best factor per cell 1.681.)
         for (int s = 1; s <= 16 && s <= nch; ++s) {
             const int cps = (nch + s - 1) / s;
             if (s > 1 && cps < 2) break;
@@ -114,6 +118,26 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
             const double e = eff[per_cu > 3 ? 3 : (int)per_cu];
             const double cost = (double)per_cu * (cps + (s > 1 ? 0.75 : 0.5)) / e;
             if (cost < best_cost * 0.99) { best_cost = cost; best = s; }   // (0.97 until r03: see the cap's note)
+        }
+    }
+    if (ksize == 3 && c.WN == 4 && one_mfma) {
+        // f16 / bf16 (r04, ABI 12): a chunk is ~3x shorter, so the fixed cost of a split workgroup (prologue,
+        // slab epilogue) weighs 3 chunks and the reduce launch's S slab reads are priced (0.2 chunk-times per
+        // S x MB of output).  Fitted to the forced-split sweep of the twenty shapes in the bf16 form
+        // (profiles/r03_splitk_sweep_bf16.txt; scratch fit: the shape-only rule's choices cost 0.911 ms there,
+        // these 0.886, the best factor per cell 0.879).  Candidates are the sweep's own columns.
+        static const double eff[4] = {1.0, 0.5, 1.0, 0.9};
+        static const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+        const double out_mb = (double)N * D * H * W * Cout * 4.0 / 1e6;
+        double best_cost = 1e300;
+        for (int i = 0; i < 10 && cand[i] <= nch; ++i) {
+            const int s = cand[i];
+            const int cps = (nch + s - 1) / s;
+            if (s > 1 && cps < 2) break;
+            const long long per_cu = (blocks * s + 255) / 256;
+            const double e = eff[per_cu > 3 ? 3 : (int)per_cu];
+            const double cost = (double)per_cu * (cps + (s > 1 ? 3.0 : 0.25)) / e + (s > 1 ? 0.2 * s * out_mb : 0.0);
+            if (cost < best_cost * 0.99) { best_cost = cost; best = s; }
         }
     }
     c.S = best;

@@ -251,7 +251,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     }
     if (p.partial != nullptr && lane < WZ_NSTAMP) {
         const size_t wgl = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
-        reinterpret_cast<unsigned long long*>(p.partial)[(wgl * 4 + wn) * WZ_NSTAMP + lane] = wz_stamps[lane];
+        // a split launch keeps its slabs in front; the dump sits behind them (tools/wz_stamps.py sizes the workspace)
+        float* dump = p.partial + (p.ksplit > 1 ? (size_t)p.ksplit * p.N * p.D * p.H * p.W * p.Cout : (size_t)0);
+        reinterpret_cast<unsigned long long*>(dump)[(wgl * 4 + wn) * WZ_NSTAMP + lane] = wz_stamps[lane];
     }
 #endif
 }

@@ -28,7 +28,7 @@ hipError_t ddpm3d_launch_attention(const float* qkv, int N, int T, int heads, in
                                    const float* bound, int bound_count, int bound_stride, float* out,
                                    hipStream_t st);
 hipError_t ddpm3d_launch_add_embedding(float* emb, const float* table, const int64_t* idx, int rows, int dim,
-                                       hipStream_t st);
+                                       int num_classes, hipStream_t st);
 hipError_t ddpm3d_launch_pool_act(const float* src, const float* A, const float* B, int act, int fast, int N, int D,
                                   int H, int W, int C, float* out, int src16, int out16, int f16, hipStream_t st);
 // probe.hip

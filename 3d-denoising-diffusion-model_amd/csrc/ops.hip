@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     for (int q0 = 0; q0 < C4; q0 += qpt) {
         const int q = q0 + (threadIdx.x % qpt);
         const int vl = threadIdx.x / qpt;
-        double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};   // fp64 sums (conv3d_params.h: gn_sums_add)
+        double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};   // fp64 sums (cf. conv3d_params.h: GnAcc, the conv epilogues' pivoted fp32 form)
         if (q < C4 && vl < vlanes) {
             for (int v = v0 + vl; v < v1; v += vlanes) {
                 const float4 t = *reinterpret_cast<const float4*>(x + ((size_t)n * voxels + v) * C + q * 4);
@@ -503,18 +503,22 @@ hipError_t ddpm3d_launch_pool_act(const float* src, const float* A, const float*
 
 // ------------------------------------------------------------ label embedding
 // emb[r][:] += table[idx[r]][:]  (unet.py:703-705: emb = emb + self.label_emb(y))
+// A label outside [0, num_classes) reads nothing (its row stays as it was): the C ABI is safe by itself,
+// the Python host still refuses such labels where nn.Embedding would.
 __global__ void add_embedding_kernel(float* __restrict__ emb, const float* __restrict__ table,
-                                     const int64_t* __restrict__ idx, int rows, int dim) {
+                                     const int64_t* __restrict__ idx, int rows, int dim, int num_classes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * dim) return;
     const int r = i / dim, j = i - r * dim;
-    emb[i] += table[(size_t)idx[r] * dim + j];
+    const int64_t c = idx[r];
+    if ((uint64_t)c < (uint64_t)num_classes) emb[i] += table[(size_t)c * dim + j];
 }
 
 hipError_t ddpm3d_launch_add_embedding(float* emb, const float* table, const int64_t* idx, int rows, int dim,
-                                       hipStream_t st) {
+                                       int num_classes, hipStream_t st) {
     const int total = rows * dim;
-    hipLaunchKernelGGL(add_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, st, emb, table, idx, rows, dim);
+    hipLaunchKernelGGL(add_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, st, emb, table, idx, rows, dim,
+                       num_classes);
     return hipGetLastError();
 }
 

@@ -28,7 +28,7 @@ WINOGRAD_OF = {PREC_F16X3: PREC_F16X3_WZ, PREC_F16: PREC_F16_WZ, PREC_BF16: PREC
 # ddpm3d_conv_desc.io_dtype bits: which activation tensors hold bf16
 IO_SRC0_BF16, IO_SRC1_BF16, IO_OUT_BF16, IO_RES_BF16 = 1, 2, 4, 8
 IO_HALF_IS_F16 = 16    # the flagged tensors hold IEEE f16 (the --use_fp16 storage), not bf16
-ABI_VERSION = 11
+ABI_VERSION = 12
 # ddpm3d_conv_desc.kernel_hint bits (launch orders of identical arithmetic; tests and A/B measurements)
 HINT_WSTAT_OFF, HINT_WSTAT_ON = 0x100, 0x200
 HINT_SPLITK_SHIFT = 16      # bits 16..21: forced split factor (measurement only, tools/splitk_sweep.py)
@@ -58,9 +58,10 @@ EXPORTS = {
     "ddpm3d_last_error": (C.c_char_p, []),
     "ddpm3d_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ddpm3d_pack_conv_weight": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
-    "ddpm3d_conv_stats_rows": (C.c_int, [C.c_int] * 7),
-    "ddpm3d_conv_workspace_bytes": (C.c_size_t, [C.c_int] * 7),
+    "ddpm3d_conv_stats_rows": (C.c_int, [C.c_int] * 8),
+    "ddpm3d_conv_workspace_bytes": (C.c_size_t, [C.c_int] * 8),
     "ddpm3d_conv3d": (C.c_int, [C.POINTER(ConvDesc), _fp]),
+    "ddpm3d_conv_kernel_family": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, C.c_int]),
     "ddpm3d_gn_finalize": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "ddpm3d_absmax": (C.c_int, [_fp, _fp, C.c_int, C.c_size_t, _fp, _fp]),

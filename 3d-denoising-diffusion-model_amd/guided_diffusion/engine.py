@@ -383,11 +383,16 @@ class _Plan:
         d = H.ConvDesc()
         lib = self.eng.lib
         cin_total = 2 if planar else sum(s.C for s in srcs)
+        if pc.wz is not None and not planar and in_mode in (H.IN_SAME, H.IN_UP):
+            pc_use = pc.wz       # Winograd-D form: same layer, same arithmetic, 2/3 of the MFMAs
+        else:
+            pc_use = pc
         if out is not None:
             d.N, d.D, d.H, d.W = N, out.D, out.H, out.W
             d.out = H.ptr(out.buf)
             if want_stats:
-                out.rows = lib.ddpm3d_conv_stats_rows(N, out.D, out.H, out.W, cin_total, pc.Cout, pc.k)
+                out.rows = lib.ddpm3d_conv_stats_rows(N, out.D, out.H, out.W, cin_total, pc.Cout, pc.k,
+                                                      pc_use.precision)
                 out.stats = torch.empty(N * out.rows * pc.Cout * 2, dtype=torch.float64,
                                         device=self.eng.device)     # fp64 (sum, sum of squares) rows
                 self.keep.append(out.stats)    # the descriptor holds a raw pointer
@@ -433,10 +438,6 @@ class _Plan:
                 raise RuntimeError("conv_step without an input bound")
             d.in_bound = bound[0].data_ptr() + 4 * bound[1]
             d.in_bound_count, d.in_bound_stride = bound[2], bound[3]
-        if pc.wz is not None and not planar and in_mode in (H.IN_SAME, H.IN_UP):
-            pc_use = pc.wz       # Winograd-D form: same layer, same arithmetic, 2/3 of the MFMAs
-        else:
-            pc_use = pc
         d.precision = pc_use.precision
         d.w_packed, d.bias = H.ptr(pc_use.w), H.ptr(pc.b)
         d.bias_stride_n = 0  # per-sample bias rows are patched in run()
@@ -446,35 +447,17 @@ class _Plan:
             # read out of bounds
             raise RuntimeError("residual has %d channels, the conv writes %d" % (res.C, pc.Cout))
         d.res = H.ptr(res.buf) if res is not None else 0
-        need = lib.ddpm3d_conv_workspace_bytes(N, d.D, d.H, d.W, d.Cin, pc.Cout, pc.k)
+        need = lib.ddpm3d_conv_workspace_bytes(N, d.D, d.H, d.W, d.Cin, pc.Cout, pc.k, pc_use.precision)
         if need:
             self.ws_descs.append(d)
             self.ws_bytes = max(self.ws_bytes, need)
         self.keep.append(d)
-        # bookkeeping for measurement: algorithmic FLOPs (2 per MAC) and the kernel
-        # instantiation the C side picks for this shape (conv3d_params.h rule)
-        wn = 4 if pc.Cout > 64 else (2 if pc.Cout > 32 else 1)
-        tile = 8 if (d.H >= 8 and d.W >= 8) else 4
+        # bookkeeping for measurement: algorithmic FLOPs (2 per MAC) and the kernel family the C side
+        # routes this descriptor to (its own answer: no copy of the routing rules here)
         flops = 2.0 * N * d.D * d.H * d.W * pc.Cout * d.Cin * pc.k ** 3
-        tag = "conv3d_p%d_k%d_wn%d_t%d" % (pc_use.precision, pc.k, wn, tile)
-        # (api.hip's rule for the one-or-two-cout kernel, conv3d_skinny.hip)
-        if (pc.k == 3 and pc.Cout <= 2 and d.in_mode == H.IN_SAME and d.C1 == 0 and not d.stats
-                and res_mode == H.RES_NONE and d.Cin in (32, 64, 128)
-                and ((pc_use.precision == H.PREC_BF16 and (d.io_dtype & H.IO_SRC0_BF16))
-                     or (pc_use.precision == H.PREC_F16
-                         and (not (d.io_dtype & H.IO_SRC0_BF16) or (d.io_dtype & H.IO_HALF_IS_F16)))
-                     or (pc_use.precision == H.PREC_F16X3 and not (d.io_dtype & H.IO_SRC0_BF16)))):
-            tag = "conv3d_p%d_k3_skinny" % pc_use.precision
-        # (conv3d_params.h ddpm3d_pw_ok: the skip connections' register-fed 1x1 GEMM, conv1x1.hip)
-        if (pc.k == 1 and d.in_mode == H.IN_SAME and aff is None and not act and not d.stats
-                and pc.Cout % 128 == 0 and d.Cin % 32 == 0 and d.C0 % 32 == 0
-                and pc_use.precision in (H.PREC_F16X3, H.PREC_F16, H.PREC_BF16)
-                and (d.C1 == 0 or bool(d.io_dtype & H.IO_SRC0_BF16) == bool(d.io_dtype & H.IO_SRC1_BF16))):
-            ts = 8 if tile == 8 else 4
-            wgs = (N * -(-d.D // (128 // (ts * ts))) * -(-d.H // ts) * -(-d.W // ts) * (pc.Cout // 128)
-                   * max(1, need // (4 * N * d.D * d.H * d.W * pc.Cout)))
-            if pc_use.precision != H.PREC_F16X3 or wgs <= 1024:
-                tag = "conv1x1_p%d_t%d" % (pc_use.precision, tile)
+        name = C.create_string_buffer(64)
+        H.check(lib.ddpm3d_conv_kernel_family(C.byref(d), name, 64))
+        tag = name.value.decode()
         self.conv_meta[len(self.steps)] = (tag, flops)
         self.steps.append((self.eng.lib.ddpm3d_conv3d, [C.byref(d), 0]))
         return d

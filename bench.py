@@ -148,6 +148,49 @@ def host_cpu():
     return model, (len(phys) or (os.cpu_count() or 1)), aff
 
 
+def cpu_quota_cores():
+    """CPU time this process's cgroup is granted, in cores (cgroup v2 cpu.max or v1 cfs quota / period), walking up
+    from the process's own cgroup; None = no quota set.  The record of what the box grants, next to what it shows."""
+    paths = []
+    try:
+        with open("/proc/self/cgroup") as f:
+            for line in f:
+                _, ctrl, rel = line.strip().split(":", 2)
+                if ctrl == "":                                  # v2
+                    d = "/sys/fs/cgroup" + rel
+                    while True:
+                        paths.append((os.path.join(d, "cpu.max"), None))
+                        if d in ("/sys/fs/cgroup", "/"):
+                            break
+                        d = os.path.dirname(d)
+                elif "cpu" in ctrl.split(","):                  # v1
+                    d = "/sys/fs/cgroup/cpu" + rel
+                    paths.append((os.path.join(d, "cpu.cfs_quota_us"), os.path.join(d, "cpu.cfs_period_us")))
+    except (OSError, ValueError):
+        pass
+    paths += [("/sys/fs/cgroup/cpu.max", None),
+              ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")]
+    best = None
+    for quota_file, period_file in paths:
+        try:
+            with open(quota_file) as f:
+                txt = f.read().split()
+            if period_file is None:
+                if not txt or txt[0] == "max":
+                    continue
+                q, per = float(txt[0]), float(txt[1])
+            else:
+                q = float(txt[0])
+                if q <= 0:
+                    continue
+                with open(period_file) as f:
+                    per = float(f.read().split()[0])
+            best = q / per if best is None else min(best, q / per)
+        except (OSError, ValueError, IndexError):
+            continue
+    return best
+
+
 def psnr_db(got, ref):
     """10 log10(range^2 / MSE), range = max - min of the reference volume."""
     mse = float(((got.double() - ref.double()) ** 2).mean())
@@ -191,6 +234,9 @@ def cpu_baseline(arch, sd, size, respacing, n_steps, threads):
         "cpu_model": cpu_model,
         "physical_cores": phys,
         "cores_available": aff,
+        # what the box's cgroup actually grants this process (None: no quota): on the pool's one-GPU boxes every
+        # host core is visible (cores_available) but the CPU-time share is this many cores
+        "cpu_quota_cores": cpu_quota_cores(),
         "kind": "port",
         "sample": "%d p_sample steps (after 1 warm-up) of the same 1x%d^3 published-arch workload, "
                   "%.2f s/step, extrapolated x%d steps" % (n_steps, size, per_step, T),
@@ -255,6 +301,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # checked before anything touches a GPU or a process group: a launcher whose world size is not --gpus
+    # (e.g. BASELINE config 3 started with --gpus 8 under a 4-rank launcher) is refused by every rank at once
+    if args.gpus != world:
+        os.dup2(real_stdout, 1)
+        raise SystemExit("[bench] --gpus %d but WORLD_SIZE %d: launch one rank per GPU (plain "
+                         "`python bench.py --gpus N` starts them itself)" % (args.gpus, world))
     # --dist-backend gloo --share-gpu: rehearsal of the multi-rank flow on a one-GPU box (all
     # ranks on cuda:0, collectives through host memory).  The real runs use RCCL ("nccl").
     gloo = args.dist_backend == "gloo"
@@ -270,17 +322,14 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-    if args.gpus != world:
-        raise SystemExit("[bench] --gpus %d but WORLD_SIZE %d: launch one rank per GPU (plain "
-                         "`python bench.py --gpus N` starts them itself)" % (args.gpus, world))
-    rccl_ranks = 1
+    collective_ranks, collective_backend = 1, None
     if use_dist:
         # the number of ranks the collective library itself sees: one all_gather of the rank ids
         ids = [torch.zeros(1, dtype=torch.int64, device=torch.device("cpu") if gloo else torch.device("cuda", dev_index))
                for _ in range(world)]
         dist.all_gather(ids, torch.full((1,), rank, dtype=torch.int64, device=ids[0].device))
         assert sorted(int(t.item()) for t in ids) == list(range(world))
-        rccl_ranks = dist.get_world_size()
+        collective_ranks, collective_backend = dist.get_world_size(), dist.get_backend()
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
     coll_dev = torch.device("cpu") if gloo else device
@@ -521,7 +570,11 @@ def main():
                        "parallelism": "independent volumes per rank (dp%d), all_gather of finished samples" % world,
                        "tflop_per_volume": round(flops_fwd * T / B / 1e12, 1),
                        "conv_arithmetic": ARITH[args.precision][1]},
-            "rccl_ranks": rccl_ranks,
+            # ranks the collective library saw in an all_gather, and which library: "nccl" = RCCL over xGMI;
+            # "gloo" = the one-GPU rehearsal through host memory.  rccl_ranks is set for RCCL runs only.
+            "collective_ranks": collective_ranks,
+            "collective_backend": collective_backend,
+            "rccl_ranks": collective_ranks if collective_backend == "nccl" else None,
             "roofline": roof,
             "exact_f32": exact,
             "parity": parity or None,
@@ -532,8 +585,12 @@ def main():
                 threads = len(os.sched_getaffinity(0))
             except Exception:
                 pass
-            # a one-GPU box exposes every host core but grants a 16-core share; more
-            # threads than that only thrash (measured: 87 s/step at 256 threads)
+            # threads = min(visible cores, the cgroup's CPU quota if one is set, --cpu-threads): a one-GPU box
+            # of the pool shows every host core and grants a share of them (the record carries both; thread
+            # sweep: tools/cpu_threads_sweep.py -> profiles/r04_cpu_threads_sweep.txt)
+            quota = cpu_quota_cores()
+            if quota is not None:
+                threads = max(1, min(threads, int(quota + 0.5)))
             threads = min(threads, args.cpu_threads)
             sd_cpu = {k: v for k, v in sd.items()}
             res["cpu_baseline"], cpu_img = cpu_baseline(arch, sd_cpu, S, respacing, args.cpu_steps, threads)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define DDPM3D_ABI_VERSION 11
+#define DDPM3D_ABI_VERSION 12
 
 enum {
     DDPM3D_OK = 0,
@@ -194,8 +194,9 @@ enum {
     /* F16X3 arithmetic on the Winograd F(2,3)-along-depth form of a 3x3x3 conv: 4 products
      * per two outputs instead of 6 (the weights are transformed at pack time, the inputs
      * while they are staged, the outputs in the epilogue).  Available for ksize 3, Cout a
-     * multiple of 128, input modes SAME / UP (8x8x2 tiles where H and W >= 8, 4x4x8 tiles -- four
-     * z-pairs per workgroup -- below); other calls return DDPM3D_ENOSUP and must use the F16X3
+     * multiple of 128, input modes SAME / UP (tiles of 128 voxels: 8x4x4 -- two z-pairs per workgroup -- where
+     * H % 8 == 0 and D % 4 == 0, otherwise 8x8x2 where H and W >= 8, and 4x4x8 -- four z-pairs --
+     * below that); other calls return DDPM3D_ENOSUP and must use the F16X3
      * packing of the same weights. */
     DDPM3D_PREC_F16X3_WZ = 3,
     /* F16 arithmetic (one MFMA per product on f16-rounded operands, as DDPM3D_PREC_F16) on the
@@ -216,10 +217,17 @@ int ddpm3d_pack_conv_weight(const float* w_oidhw, int Cout, int Cin, int ksize, 
                             void* w_packed, void* stream);
 
 /* rows per sample of the statistics buffer this conv writes, and the scratch
- * it needs (both depend on how the shape is tiled / split) */
-int ddpm3d_conv_stats_rows(int N, int D, int H, int W, int Cin, int Cout, int ksize);
-size_t ddpm3d_conv_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int ksize);
+ * it needs (both depend on how the shape is tiled / split; `precision` = the DDPM3D_PREC_* of the call
+ * since ABI 12: the split over Cin is chosen per arithmetic mode) */
+int ddpm3d_conv_stats_rows(int N, int D, int H, int W, int Cin, int Cout, int ksize, int precision);
+size_t ddpm3d_conv_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int ksize, int precision);
 int ddpm3d_conv3d(const ddpm3d_conv_desc* desc, void* stream);
+/* Which kernel family ddpm3d_conv3d runs this descriptor on, as a NUL-terminated name:
+ * "conv3d_p<precision>_k<ksize>_wn<waves along Cout>_t<tile width>" (direct and Winograd-D forms),
+ * "conv1x1_p<precision>_t<tile width>" (the register-fed 1x1 GEMM), "conv3d_p<precision>_k3_skinny" (Cout <= 2).
+ * Validates like ddpm3d_conv3d (the split-K workspace excepted) and launches nothing: measurement
+ * bookkeeping for callers that attribute time per family (ABI 12). */
+int ddpm3d_conv_kernel_family(const ddpm3d_conv_desc* desc, char* name, int name_len);
 
 /*
  * GroupNorm32 statistics -> affine coefficients (nn.py:93-100: 32 groups,
@@ -280,8 +288,9 @@ int ddpm3d_pool_act(const void* src, const float* aff_a, const float* aff_b, int
                     int H, int W, int C, void* out, int io_dtype, void* stream);
 
 /* Class conditioning (unet.py:476-478, :703-705): emb[r][:] += table[idx[r]][:] with table =
- * label_emb.weight [num_classes][dim] and idx = the batch's labels (int64, device; each in
- * [0, num_classes) -- validated by the caller, as nn.Embedding does on the host side). */
+ * label_emb.weight [num_classes][dim] and idx = the batch's labels (int64, device).  A label outside
+ * [0, num_classes) adds nothing to its row (never an out-of-bounds read, ABI 12); a caller that wants
+ * nn.Embedding's error checks the labels itself, as the Python host does once per sampling loop. */
 int ddpm3d_add_embedding(float* emb, const float* table, const int64_t* idx, int rows, int dim, int num_classes,
                          void* stream);
 

@@ -255,6 +255,31 @@ def resblock(sd, p, x, emb, updown, film):
     return x + h
 
 
+# Query rows per block of the attention product.  The reference materialises the whole (T x T) weight
+# matrix (unet.py:349-353); at BASELINE config 5's T = 32 768 that is 4.3 GB per head, so the oracle walks the
+# QUERY axis in blocks.  A softmax row depends on its own query only, so every row is computed from exactly the
+# same numbers as in the materialised form (tests/test_oracle_golden.py pins the blocked form to the
+# reference's own `tiny_attn` outputs with a block smaller than T).
+ATTN_QUERY_BLOCK = 2048
+
+
+def qkv_attention(q, k, v, block=None, dtype=None):
+    """softmax((q s)^T (k s)) v per (batch x head) row of q, k, v [B, ch, T]; s = ch^-1/4 (unet.py:346-353).
+    block: query rows per pass (None = ATTN_QUERY_BLOCK).  dtype float64 = an fp64 evaluation for tests."""
+    ch, length = q.shape[1], q.shape[2]
+    s = 1 / math.sqrt(math.sqrt(ch))
+    block = block or ATTN_QUERY_BLOCK
+    if dtype is not None:
+        q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    out = torch.empty_like(q)
+    ks = k * s
+    for t0 in range(0, length, block):
+        w = torch.einsum("bct,bcs->bts", q[:, :, t0:t0 + block] * s, ks)
+        w = torch.softmax(w.float() if dtype is None else w, dim=-1).type(w.dtype)
+        out[:, :, t0:t0 + block] = torch.einsum("bts,bcs->bct", w, v)
+    return out
+
+
 def attention(sd, p, x, n_heads, new_order=False):
     # unet.py:296-305; QKVAttentionLegacy :337-354, or (new_order) QKVAttention :361-389
     b, c = x.shape[:2]
@@ -267,10 +292,7 @@ def attention(sd, p, x, n_heads, new_order=False):
         q, k, v = (t.reshape(b * n_heads, ch, length) for t in qkv.chunk(3, dim=1))
     else:
         q, k, v = qkv.reshape(b * n_heads, ch * 3, length).split(ch, dim=1)
-    s = 1 / math.sqrt(math.sqrt(ch))
-    w = torch.einsum("bct,bcs->bts", q * s, k * s)
-    w = torch.softmax(w.float(), dim=-1).type(w.dtype)
-    a = torch.einsum("bts,bcs->bct", w, v).reshape(b, -1, length)
+    a = qkv_attention(q, k, v).reshape(b, -1, length)
     h = F.conv1d(a, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
     return (xf + h).reshape(b, c, *spatial)
 

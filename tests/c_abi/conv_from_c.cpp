@@ -65,9 +65,13 @@ int main(void) {
     CHECK_HIP(hipMemcpy(dB, B, sizeof(float) * Ci, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(dres, res, sizeof(float) * vox * Co, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(dbound, &amax, sizeof(float), hipMemcpyHostToDevice));   /* upper bound of |act| */
-    const int rows = ddpm3d_conv_stats_rows(N, D, H, W, Ci, Co, 3);
+    /* sized for the larger of the two arithmetic modes run below (the split over Cin is chosen per mode) */
+    int rows = ddpm3d_conv_stats_rows(N, D, H, W, Ci, Co, 3, DDPM3D_PREC_F16X3);
+    if (ddpm3d_conv_stats_rows(N, D, H, W, Ci, Co, 3, DDPM3D_PREC_F32) != rows) { printf("FAIL: rows differ by mode\n"); return 1; }
     CHECK_HIP(hipMalloc(&dstats, sizeof(double) * Co * rows * 2));
-    const size_t ws_bytes = ddpm3d_conv_workspace_bytes(N, D, H, W, Ci, Co, 3);
+    size_t ws_bytes = ddpm3d_conv_workspace_bytes(N, D, H, W, Ci, Co, 3, DDPM3D_PREC_F16X3);
+    if (ddpm3d_conv_workspace_bytes(N, D, H, W, Ci, Co, 3, DDPM3D_PREC_F32) > ws_bytes)
+        ws_bytes = ddpm3d_conv_workspace_bytes(N, D, H, W, Ci, Co, 3, DDPM3D_PREC_F32);
     void* dws = NULL;
     if (ws_bytes) CHECK_HIP(hipMalloc(&dws, ws_bytes));
     hipStream_t st;

@@ -248,6 +248,40 @@ def gen_sampler_published250():
     save("sampler_published250.npz", **out)
 
 
+def gen_sampler250_64(threads=6):
+    """BASELINE config 2 itself: the PUBLISHED architecture, 1x1x64x64x64, all 250 steps of
+    timestep_respacing="250", injected noise (about one CPU-hour of the reference: 12-15 s per
+    step).  Keeps the samples after 50 and 150 completed steps, the final sample and the per-step
+    trace; partial results are written as they arrive."""
+    torch.set_num_threads(threads)
+    shape = (1, 1, 64, 64, 64)
+    model, diff = ref_su.sr_create_model_and_diffusion(**flags(**dict(PUBLISHED, timestep_respacing="250")))
+    load_synth(model)
+    T = diff.num_timesteps
+    assert T == 250
+    draws = synth.synth_noise(shape, T + 1, seed=10)
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234))
+    keep_at = (1, 50, 150)
+    out, trace = {}, []
+    import time
+    t0 = time.time()
+    with _InjectNoise(draws[1:]), torch.no_grad():
+        gen = diff.p_sample_loop_progressive(model, shape, torch.from_numpy(draws[0]),
+                                             model_kwargs={"low_res": lr})
+        for i, o in enumerate(gen):
+            s = o["sample"]
+            trace.append((float(s.mean()), float(o["pred_xstart"].mean()), float(s.std())))
+            if i + 1 in keep_at:
+                out["after%d" % (i + 1)] = s.numpy().copy()
+                np.savez(os.path.join("/tmp", "sampler250_64_partial.npz"), trace=np.array(trace), **out)
+            last = o
+            if (i + 1) % 10 == 0:
+                print("sampler250_64: step", i + 1, trace[-1], "%.0f s" % (time.time() - t0), flush=True)
+    out["sample"] = last["sample"].numpy()
+    out["trace"] = np.array(trace, dtype=np.float64)
+    save("sampler250_64.npz", **out)
+
+
 def gen_script_helpers():
     """The pure helpers of the reference's inference script (scripts/test.py:248-262 Hann window,
     :283-301 patch start positions).  The script itself cannot be imported here (it needs tifffile /
@@ -495,3 +529,5 @@ if __name__ == "__main__":
         gen_api_extras()
     if "sampler250" in which:       # ~10 CPU-minutes; not part of the default list
         gen_sampler_published250()
+    if "sampler250_64" in which:    # ~1 CPU-hour (BASELINE config 2 at full size); not part of the default list
+        gen_sampler250_64()

@@ -88,8 +88,8 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
     else:
         out = torch.full((N, co, D, Hh, W), float("nan"), dtype=torch.float32, device=dev)
     d.out, d.out_layout = H.ptr(out), out_layout
-    rows = lib.ddpm3d_conv_stats_rows(N, D, Hh, W, ci, co, k)
-    need = lib.ddpm3d_conv_workspace_bytes(N, D, Hh, W, ci, co, k)
+    rows = lib.ddpm3d_conv_stats_rows(N, D, Hh, W, ci, co, k, d.precision)
+    need = lib.ddpm3d_conv_workspace_bytes(N, D, Hh, W, ci, co, k, d.precision)
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
     if need:
         d.workspace, d.workspace_bytes = H.ptr(ws), need

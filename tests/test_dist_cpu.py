@@ -69,3 +69,28 @@ def test_two_ranks_gloo_match_single_process(tmp_path):
         assert [i for i, _ in collected] == list(range(n_items))     # every rank ends with all samples
         for i, t in collected:
             assert torch.equal(t, expect[i])                         # same as a 1-rank run
+
+
+def test_config3_partition_is_even_on_eight_ranks():
+    """BASELINE config 3 (64 volumes of 64^3 over 8 GPUs, scripts/test.py:235-246): eight volumes per rank,
+    rank-strided, no padding round, every volume exactly once."""
+    seen = []
+    for r in range(8):
+        mine = dist_util.partition(64, r, 8)
+        assert mine == list(range(r, 64, 8)) and len(mine) == 8 and None not in mine
+        seen += mine
+    assert sorted(seen) == list(range(64))
+
+
+def test_bench_refuses_a_launcher_of_another_world_size():
+    """`bench.py --gpus 8` under a launcher that hands over WORLD_SIZE != 8 exits non-zero BEFORE any GPU or
+    process-group call (runs on the CPU-only build box), naming both numbers; stdout stays empty."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="4")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--batch", "8"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "--gpus 8" in r.stderr and "WORLD_SIZE 4" in r.stderr
+    assert r.stdout.strip() == ""

@@ -461,7 +461,7 @@ def test_groupnorm_with_large_mean(hc, ratio):
     """un-normalised PET counts (scripts/test.py:201-203 feeds them raw) put tensors
     whose |mean| is tens to hundreds of standard deviations in front of a GroupNorm.  With fp32 partial
     sums E[x^2] - mean^2 loses ratio^2 x 1e-7 of the variance to cancellation (1e-2 at ratio 300); the
-    partial sums are fp64 (conv3d_params.h: gn_sums_add).  Both producers of statistics -- the
+    partial sums are fp64 (conv3d_params.h: struct GnAcc -- pivoted fp32 accumulation, one fp64 conversion).  Both producers of statistics -- the
     stand-alone pass and a conv epilogue -- then finalize -> the next conv's prologue, against
     group_norm evaluated in fp64 (nn.py:93-100), at the 1e-4 bar on the NORMALISED output's scale."""
     import guided_diffusion._hip as H
@@ -529,7 +529,7 @@ def test_conv3d_splitk_with_pooled_paths(hc):
     """Split-K path with the prologue pool, the pooled residual and statistics from the reduce kernel."""
     import guided_diffusion._hip as H
     lib = H.load()
-    assert lib.ddpm3d_conv_workspace_bytes(1, 12, 4, 4, 128, 128, 3) > 0   # this shape does split
+    assert lib.ddpm3d_conv_workspace_bytes(1, 12, 4, 4, 128, 128, 3, H.PREC_F16X3) > 0   # this shape does split
     x = rnd(1, 128, 12, 8, 8, seed=1)
     gamma, beta = 1 + 0.1 * rnd(128, seed=3), 0.1 * rnd(128, seed=4)
     w = rnd(128, 128, 3, 3, 3, seed=2, scale=0.03)
@@ -641,6 +641,34 @@ def test_attention_core_vs_legacy_reference(hc, N, T, heads, ch, scale, precisio
         H.check(lib.ddpm3d_attention(H.ptr(qd), N, T, heads, ch, H.ptr(out0), H.stream()))
         torch.cuda.synchronize()
         assert torch.equal(out0, out)
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("T,heads", [(4096, 3), (32768, 1)])
+def test_attention_core_long_sequences_vs_blocked_cpu_softmax(hc, T, heads, precision):
+    """The streaming kernel at the sequence lengths of the published network's attention levels -- T = 4 096 and
+    BASELINE config 5's T = 32 768 (1 024 key tiles per query block, with the running-max rescale skipped where
+    no lane needs it) -- against an INDEPENDENT evaluation: the oracle's query-blocked softmax in fp64 on the CPU
+    (oracle/unet_ref.py: qkv_attention, pinned to the reference's attention outputs in test_oracle_golden.py).
+    ch = 64 as in the published configuration; both arithmetics of the two products; same 1e-5 bar as at T <= 512."""
+    import guided_diffusion._hip as H
+    from oracle import unet_ref
+    lib = H.load()
+    ch, N = 64, 1
+    qkv = rnd(N, heads * 3 * ch, T, seed=11)                        # reference layout (N, H*3*C, T)
+    q, k, v = qkv.reshape(N * heads, ch * 3, T).split(ch, dim=1)
+    ref = unet_ref.qkv_attention(q, k, v, block=1024, dtype=torch.float64).reshape(N, -1, T)
+    qd = qkv.permute(0, 2, 1).contiguous().cuda()
+    out = torch.full((N, T, heads * ch), float("nan"), device="cuda")
+    qb = qd.abs().reshape(N, -1).amax(dim=1).contiguous()
+    H.check(lib.ddpm3d_attention_p(H.ptr(qd), N, T, heads, ch, precision, H.ptr(qb), 1, 1, H.ptr(out), H.stream()))
+    torch.cuda.synchronize()
+    got = out.permute(0, 2, 1).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_err(got, ref.numpy()) < 1e-5
+    # per query position too: at this T the averaged-out values are small against the global maximum
+    err = np.abs(got - ref.numpy()).max(axis=1) / np.abs(ref.numpy()).max(axis=1)
+    assert err.max() < 1e-4
 
 
 def test_attention_rejects_unsupported_head_width(hc):

@@ -128,7 +128,9 @@ def test_bench_starts_its_own_ranks():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["scaling"] == "weak"
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
+    # the collective library that ran is named: this rehearsal is gloo, so the line claims no RCCL ranks
+    assert rec["collective_ranks"] == 2 and rec["collective_backend"] == "gloo" and rec["rccl_ranks"] is None
     assert rec["steps"] == 1 and rec["value"] > 0
     # a launcher that hands over the wrong world size is refused, not silently accepted
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1"],

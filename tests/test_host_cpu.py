@@ -51,16 +51,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.ddpm3d_packed_weight_bytes(8, 8, 2, 0) == 0 and lib.ddpm3d_packed_weight_bytes(8, 8, 3, 7) == 0
     lib.ddpm3d_conv_workspace_bytes.restype = ctypes.c_size_t
     # 64^3 level: 2048 tiles of 128 voxels (2x8x8) fill the chip, no split, one row per tile
-    assert lib.ddpm3d_conv_stats_rows(1, 64, 64, 64, 128, 128, 3) == 32 * 8 * 8
+    assert lib.ddpm3d_conv_stats_rows(1, 64, 64, 64, 128, 128, 3, 3) == 32 * 8 * 8
     # 64x32x32 level: 128-voxel tiles (2x8x8)
-    assert lib.ddpm3d_conv_stats_rows(1, 64, 32, 32, 128, 128, 3) == 32 * 4 * 4
-    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 64, 64, 128, 128, 3) == 0
+    assert lib.ddpm3d_conv_stats_rows(1, 64, 32, 32, 128, 128, 3, 3) == 32 * 4 * 4
+    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 64, 64, 128, 128, 3, 3) == 0
     # 64x4x4 level: 8 voxel tiles -> split over Cin; the reduce kernel's rows shrink from 16 to 4
     # voxels on this level so that it still launches >= 1024 workgroups (256 rows x 2 quad blocks)
-    assert lib.ddpm3d_conv_stats_rows(1, 64, 4, 4, 512, 512, 3) == 256
+    assert lib.ddpm3d_conv_stats_rows(1, 64, 4, 4, 512, 512, 3, 3) == 256
     # eight samples of the same level: 8 x 64 rows x 2 quad blocks of 16 voxels already fill it
-    assert lib.ddpm3d_conv_stats_rows(8, 64, 4, 4, 512, 512, 3) == 64
-    ws = lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 512, 512, 3)
+    assert lib.ddpm3d_conv_stats_rows(8, 64, 4, 4, 512, 512, 3, 3) == 64
+    ws = lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 512, 512, 3, 3)
     assert ws > 0 and ws % (1024 * 512 * 4) == 0
 
 
@@ -74,11 +74,13 @@ def test_split_rule_and_prepass_argument_checks_without_a_gpu():
     for (D, H, W, ci, co, k) in [(64, 4, 4, 1024, 384, 3), (64, 4, 4, 512, 512, 3), (64, 8, 8, 768, 384, 3),
                                  (64, 4, 4, 1024, 512, 1), (64, 8, 8, 768, 384, 1), (64, 16, 16, 512, 256, 1)]:
         out_bytes = D * H * W * co * 4
-        ws = lib.ddpm3d_conv_workspace_bytes(1, D, H, W, ci, co, k)
-        assert ws % out_bytes == 0
-        S = ws // out_bytes
-        assert S <= (16 if k == 3 else ci // 16), (D, H, W, ci, co, k, S)
-    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 1024, 384, 3) == 16 * 64 * 4 * 4 * 384 * 4
+        for prec in ((3, 6, 0) if k == 3 else (1, 5, 0)):      # the rule is per arithmetic mode since ABI 12
+            ws = lib.ddpm3d_conv_workspace_bytes(1, D, H, W, ci, co, k, prec)
+            assert ws % out_bytes == 0
+            S = ws // out_bytes
+            assert S <= (16 if k == 3 else ci // 16), (D, H, W, ci, co, k, prec, S)
+    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 1024, 384, 3, 3) == 16 * 64 * 4 * 4 * 384 * 4
+    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 1024, 384, 3, 7) == 0      # unknown precision
     lib.ddpm3d_pool_act.restype = ctypes.c_int
     vp = ctypes.c_void_p
     lib.ddpm3d_pool_act.argtypes = [vp, vp, vp] + [ctypes.c_int] * 7 + [vp, ctypes.c_int, vp]
@@ -259,3 +261,20 @@ def test_class_cond_and_new_attention_order_layouts_match_reference():
         model, _ = su.create_model_and_diffusion(**dict(f2, **over))
         assert model.topology.new_attention_order
         assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == ref[tag], tag
+
+
+def test_integration_doc_binds_the_current_abi():
+    """INTEGRATION.md's condensed binding starts with `assert lib.ddpm3d_abi_version() == N`: N is the header's
+    and the Python binding's ABI version (a copy-paste of the documented stub must not fail on its first line)."""
+    import re
+    from conftest import ROOT
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"ddpm3d_abi_version\(\) == (\d+)", doc)
+    assert m, "INTEGRATION.md no longer shows the ABI assertion"
+    hdr = open(os.path.join(ROOT, "include", "ddpm3d.h")).read()
+    h = re.search(r"#define DDPM3D_ABI_VERSION (\d+)", hdr)
+    assert int(m.group(1)) == int(h.group(1)) == _hip.ABI_VERSION
+    # and the README's layout table names the same version
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    r = re.search(r"ABI version (\d+)", readme)
+    assert r and int(r.group(1)) == _hip.ABI_VERSION

@@ -47,9 +47,9 @@ def main():
     wp = torch.empty(lib.ddpm3d_packed_weight_bytes(a.cout, a.cin, a.k, a.precision), dtype=torch.uint8, device=dev)
     H.check(lib.ddpm3d_pack_conv_weight(H.ptr(w), a.cout, a.cin, a.k, a.precision, H.ptr(wp), H.stream()))
     out = torch.empty(N, D, Hh, W, a.cout, device=dev)
-    rows = lib.ddpm3d_conv_stats_rows(N, D, Hh, W, a.cin, a.cout, a.k)
+    rows = lib.ddpm3d_conv_stats_rows(N, D, Hh, W, a.cin, a.cout, a.k, a.precision)
     stats = torch.empty(N, a.cout, rows, 2, dtype=torch.float64, device=dev)
-    need = lib.ddpm3d_conv_workspace_bytes(N, D, Hh, W, a.cin, a.cout, a.k)
+    need = lib.ddpm3d_conv_workspace_bytes(N, D, Hh, W, a.cin, a.cout, a.k, a.precision)
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
     d = H.ConvDesc()
     d.N, d.D, d.H, d.W, d.Cin, d.Cout, d.ksize, d.in_mode = N, D, Hh, W, a.cin, a.cout, a.k, H.IN_SAME

@@ -84,7 +84,7 @@ def main():
                 times[n].append(e0.elapsed_time(e1) / a.iters)
         d.kernel_hint = 0
         med = {n: sorted(v)[len(v) // 2] for n, v in times.items()}
-        ws = lib.ddpm3d_conv_workspace_bytes(d.N, d.D, d.H, d.W, d.Cin, d.Cout, d.ksize)
+        ws = lib.ddpm3d_conv_workspace_bytes(d.N, d.D, d.H, d.W, d.Cin, d.Cout, d.ksize, d.precision)
         split = ws // (d.N * d.D * d.H * d.W * d.Cout * 4) if ws else 1
         best = min(med, key=med.get)
         print("%-6s %-12s %-12s %2d | %s   best %s (%.0f TFLOP/s)" % (

@@ -73,7 +73,7 @@ def main():
             continue
         d = args[0]._obj
         vox = d.D * d.H * d.W
-        ws = lib.ddpm3d_conv_workspace_bytes(d.N, d.D, d.H, d.W, d.Cin, d.Cout, d.ksize)
+        ws = lib.ddpm3d_conv_workspace_bytes(d.N, d.D, d.H, d.W, d.Cin, d.Cout, d.ksize, d.precision)
         split = ws // (d.N * vox * d.Cout * 4) if ws else 1
         print("%3d  %-24s %-6s %-12s %-14s %2d  %8.3f %8.1f" % (
             j, tag, IN_MODES.get(d.in_mode, "?"), "%d->%d" % (d.Cin, d.Cout), "%dx%dx%d" % (d.D, d.H, d.W),

@@ -94,7 +94,7 @@ def main():
         cells = []
         for s in SPLITS:
             cells.append("%7.4f" % run(s << H.HINT_SPLITK_SHIFT) if s <= nch and (s == 1 or (nch + s - 1) // s >= 1) else "      -")
-        need = lib.ddpm3d_conv_workspace_bytes(1, D, Hh, W, ci, co, ks)
+        need = lib.ddpm3d_conv_workspace_bytes(1, D, Hh, W, ci, co, ks, d.precision)
         s_auto = need // (out.numel() * 4) if need else 1
         print("%-22s %5.4f (S=%d) | %s" % ("%d->%d @ %dx%dx%d" % (ci, co, D, Hh, W), auto, s_auto, "  ".join(cells)))
 

@@ -48,11 +48,19 @@ def main():
     H.check(lib.ddpm3d_pack_conv_weight(H.ptr(w), a.cout, a.cin, 3, a.precision, H.ptr(wp), H.stream()))
     out = torch.empty(1, D, Hh, W, a.cout, device=dev)
     res = torch.randn(1, D, Hh, W, a.cout, device=dev, generator=g)
-    rows = lib.ddpm3d_conv_stats_rows(1, D, Hh, W, a.cin, a.cout, 3)
+    rows = lib.ddpm3d_conv_stats_rows(1, D, Hh, W, a.cin, a.cout, 3, a.precision)
     stats = torch.empty(1, a.cout, rows, 2, dtype=torch.float64, device=dev)
-    assert lib.ddpm3d_conv_workspace_bytes(1, D, Hh, W, a.cin, a.cout, 3) == 0, "unsplit shapes only"
-    nwg = (D // 2) * ((Hh + 7) // 8) * ((W + 7) // 8) * (a.cout // 128)
-    stamps = torch.zeros(nwg * 4 * NS, dtype=torch.int64, device=dev)
+    # a split launch keeps its slabs at the front of the workspace; the kernel dumps the stamps behind them
+    need = lib.ddpm3d_conv_workspace_bytes(1, D, Hh, W, a.cin, a.cout, 3, a.precision)
+    S = max(1, need // (4 * D * Hh * W * a.cout))
+    if Hh >= 8 and W >= 8:
+        tiles = ((D + 1) // 2) * ((Hh + 7) // 8) * ((W + 7) // 8)      # 8x8x2 (8x4x4 tiles the same count)
+    else:
+        tiles = ((D + 7) // 8) * ((Hh + 3) // 4) * ((W + 3) // 4)      # 4x4x8
+    nwg = tiles * (a.cout // 128) * S
+    assert -(-(a.cin // 16) // S) <= 8, "at most 8 chunks per workgroup fit the stamp record"
+    ws = torch.zeros(need // 8 + nwg * 4 * NS, dtype=torch.int64, device=dev)
+    stamps = ws[need // 8:]
     d = H.ConvDesc()
     d.N, d.D, d.H, d.W, d.Cin, d.Cout, d.ksize, d.in_mode = 1, D, Hh, W, a.cin, a.cout, 3, H.IN_SAME
     d.src0, d.C0 = H.ptr(x), a.cin
@@ -66,7 +74,7 @@ def main():
     xin = torch.nn.functional.silu(x * A[:, None, None, None, :] + B[:, None, None, None, :])
     bound = xin.abs().reshape(1, -1).amax(dim=1, keepdim=True).contiguous()
     d.in_bound, d.in_bound_count, d.in_bound_stride = H.ptr(bound), 1, 1
-    d.workspace, d.workspace_bytes = H.ptr(stamps), stamps.numel() * 8     # the stamp dump
+    d.workspace, d.workspace_bytes = H.ptr(ws), ws.numel() * 8             # slabs (if any) + the stamp dump
     for _ in range(20):                                                    # reach the sustained clock
         H.check(lib.ddpm3d_conv3d(C.byref(d), H.stream()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -79,11 +87,12 @@ def main():
     if not s[:, :, 43].all():
         print("no stamps: this library was not built with -DDDPM3D_WZ_STAMPS")
         return
-    nch = a.cin // 16
+    nch = -(-(a.cin // 16) // S)      # chunks per workgroup
     life = s[:, :, 43] - s[:, :, 0]
     ghz = None
-    print("# conv3d_wz_kernel stamps, %d->%d @ %dx%dx%d, precision %d%s: %.3f ms (instrumented), %d workgroups"
-          % (a.cin, a.cout, D, Hh, W, a.precision, ", residual" if a.res else "", ms, nwg))
+    print("# conv3d_wz_kernel stamps, %d->%d @ %dx%dx%d, precision %d%s: %.3f ms (instrumented; conv + reduce if split), "
+          "%d workgroups, split %d, %d chunks each"
+          % (a.cin, a.cout, D, Hh, W, a.precision, ", residual" if a.res else "", ms, nwg, S, nch))
     span = s[:, :, 43].max() - s[:, :, 0].min()
     rt = s[:, :, 46]
     print("kernel span %d cycles; shader clock ~%.3f GHz (span / event time)" % (span, span / (ms * 1e6)))
@@ -93,6 +102,8 @@ def main():
         print("%-44s median %8.0f  mean %8.0f  p10 %8.0f  p90 %8.0f" % (name, np.median(v), v.mean(),
                                                                         np.percentile(v, 10), np.percentile(v, 90)))
     stat("wave lifetime", life)
+    stat("wave start after the first wave's start", s[:, :, 0] - s[:, :, 0].min())
+    stat("wave end after the first wave's start", s[:, :, 43] - s[:, :, 0].min())
     stat("prologue (entry -> first stage issued)", s[:, :, 1] - s[:, :, 0])
     c = np.arange(nch)
     b1 = s[:, :, 3 + 5 * c] - s[:, :, 2 + 5 * c]
