@@ -108,19 +108,19 @@ static int conv_prepare(const ddpm3d_conv_desc* d, ConvK& k, ConvCfg& c, int& ro
         return fail(DDPM3D_EINVAL, "conv3d: out_layout %d", d->out_layout);
 
     c = ddpm3d_conv_cfg(d->N, d->D, d->H, d->W, d->Cin, d->Cout, d->ksize, d->precision);
-    if (d->kernel_hint & DDPM3D_HINT_SPLITK_MASK) {
-        // measurement only (tools/splitk_sweep.py): force the split factor; the caller sizes the workspace
-        // for it and passes no statistics (their row count follows the library's own choice)
-        const int s_forced = (d->kernel_hint & DDPM3D_HINT_SPLITK_MASK) >> DDPM3D_HINT_SPLITK_SHIFT;
+    if (d->kernel_hint & (DDPM3D_HINT_SPLITK_MASK | DDPM3D_HINT_SPLITK_TWO_LAUNCH)) {
+        // tests and measurements (tools/splitk_sweep.py): force the split factor and / or the two-launch combine;
+        // the caller sizes statistics and workspace with ddpm3d_conv_plan on the same descriptor
+        int s_forced = (d->kernel_hint & DDPM3D_HINT_SPLITK_MASK) >> DDPM3D_HINT_SPLITK_SHIFT;
         const int nch = ddpm3d_cin_pad(d->Cin) / DDPM3D_CONV_CK;
-        if (d->stats || s_forced > nch || c.WN != 4)
-            return fail(DDPM3D_EINVAL, "conv3d: a forced split factor needs Cout > 64, no statistics, S <= Cin / 16");
-        c.S = s_forced;
-        c.workspace_bytes = s_forced > 1 ? (size_t)s_forced * d->N * d->D * d->H * d->W * d->Cout * sizeof(float) : 0;
-        const long long vox = (long long)d->D * d->H * d->W;
-        c.stats_rows = s_forced > 1 ? (int)((vox + c.reduce_vox - 1) / c.reduce_vox)
-                                    : c.tilesZ * c.tilesY * c.tilesX * (4 / c.WN);   // (the reduce kernel's grid)
+        if (s_forced == 0) s_forced = c.S;
+        if (s_forced > nch || (s_forced != c.S && c.WN != 4))
+            return fail(DDPM3D_EINVAL, "conv3d: a forced split factor needs Cout > 64 and S <= Cin / 16");
+        ddpm3d_conv_cfg_split(c, s_forced, !(d->kernel_hint & DDPM3D_HINT_SPLITK_TWO_LAUNCH), d->N, d->D, d->H, d->W, d->Cout);
     }
+    // (the exact mode's four-byte slab stores and the NCDHW edge keep the reduce launch)
+    if (c.fused && (d->out_layout != DDPM3D_OUT_NDHWC))
+        ddpm3d_conv_cfg_split(c, c.S, false, d->N, d->D, d->H, d->W, d->Cout);
     if (prec_wz(d->precision) &&
         !(wz_layer_ok(d->Cout, d->Cin, d->ksize) && c.WN == 4 && c.MT == 4 &&
           (d->in_mode == DDPM3D_IN_SAME || d->in_mode == DDPM3D_IN_UP)))
@@ -162,7 +162,8 @@ static int conv_prepare(const ddpm3d_conv_desc* d, ConvK& k, ConvCfg& c, int& ro
     k.chunks_per_split = (k.CinPad / DDPM3D_CONV_CK + c.S - 1) / c.S;
     // 1x1 convs: whole 32-channel blocks per split (conv1x1.hip walks K in those; any range suits the general kernel)
     if (d->ksize == 1 && c.S > 1) k.chunks_per_split = (k.chunks_per_split + 1) & ~1;
-    k.partial = (float*)d->workspace;
+    k.tickets = c.fused ? (unsigned*)d->workspace : nullptr;
+    k.partial = (float*)((char*)d->workspace + c.ticket_bytes);
     {
         // extents for the kernel's buffer descriptors (32-bit offsets)
         const bool dbl = d->in_mode == DDPM3D_IN_POOL || d->in_mode == DDPM3D_IN_STRIDE2;
@@ -215,8 +216,21 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         return launched(ddpm3d_launch_conv_skinny(k, d->precision, (hipStream_t)stream), "conv3d (skinny)");
     const int rc = route == ROUTE_PW ? launched(ddpm3d_launch_conv_pw(k, c, (hipStream_t)stream), "conv3d (1x1)")
                                      : launched(ddpm3d_launch_conv(k, c, (hipStream_t)stream), "conv3d");
-    if (rc != DDPM3D_OK || c.S == 1) return rc;
+    if (rc != DDPM3D_OK || c.S == 1 || c.fused) return rc;
     return launched(ddpm3d_launch_splitk_reduce(k, (hipStream_t)stream), "conv3d split-K reduce");
+}
+
+int ddpm3d_conv_plan(const ddpm3d_conv_desc* d, int* stats_rows, size_t* workspace_bytes, int* split, int* fused) {
+    ConvK k;
+    ConvCfg c;
+    int route = ROUTE_GENERAL;
+    const int ok = conv_prepare(d, k, c, route, false);
+    if (ok != DDPM3D_OK) return ok;
+    if (stats_rows) *stats_rows = c.stats_rows;
+    if (workspace_bytes) *workspace_bytes = c.workspace_bytes;
+    if (split) *split = c.S;
+    if (fused) *fused = c.fused;
+    return DDPM3D_OK;
 }
 
 int ddpm3d_conv_kernel_family(const ddpm3d_conv_desc* d, char* name, int name_len) {

@@ -109,6 +109,13 @@ __device__ __forceinline__ StageLaneT<G> stage_lane(const ConvK& p, int lt, int 
     return s;
 }
 
+// the activation scale, once it is known (stage_lane was given 1)
+template <class G>
+__device__ __forceinline__ void stage_lane_scale(const ConvK& p, StageLaneT<G>& s, float scale) {
+    s.scale = scale;
+    s.km = p.act ? -1.44269504088896341f / scale : 0.0f;
+}
+
 // Slots of halo voxels outside H x W are zero for every item: written once, never again.
 // nimages = tile images at lds_images (each G::NZP pair images)
 template <class G>

@@ -32,6 +32,7 @@ ABI_VERSION = 12
 # ddpm3d_conv_desc.kernel_hint bits (launch orders of identical arithmetic; tests and A/B measurements)
 HINT_WSTAT_OFF, HINT_WSTAT_ON = 0x100, 0x200
 HINT_SPLITK_SHIFT = 16      # bits 16..21: forced split factor (measurement only, tools/splitk_sweep.py)
+HINT_SPLITK_TWO_LAUNCH = 0x400   # combine a split conv's slabs in a reduce launch of its own (tests, A/B)
 HINT_WZ_ORDER_SHIFT = 12     # bits 12..14: tap issue order of the f16x3 Winograd-D kernel (A/B measurements)
 
 _fp = C.c_void_p
@@ -62,6 +63,8 @@ EXPORTS = {
     "ddpm3d_conv_workspace_bytes": (C.c_size_t, [C.c_int] * 8),
     "ddpm3d_conv3d": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "ddpm3d_conv_kernel_family": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, C.c_int]),
+    "ddpm3d_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]),
     "ddpm3d_gn_finalize": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "ddpm3d_absmax": (C.c_int, [_fp, _fp, C.c_int, C.c_size_t, _fp, _fp]),
@@ -125,6 +128,13 @@ class Ddpm3dError(RuntimeError):
 def check(rc):
     if rc != 0:
         raise Ddpm3dError(rc, load().ddpm3d_last_error().decode())
+
+
+def conv_plan(desc):
+    """(stats rows, workspace bytes, split factor, combined inside the launch) of ddpm3d_conv3d on this descriptor"""
+    rows, ws, split, fused = C.c_int(0), C.c_size_t(0), C.c_int(0), C.c_int(0)
+    check(load().ddpm3d_conv_plan(C.byref(desc), C.byref(rows), C.byref(ws), C.byref(split), C.byref(fused)))
+    return rows.value, ws.value, split.value, bool(fused.value)
 
 
 def stream():

@@ -21,6 +21,7 @@ for every step of the schedule.
 import collections
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -66,7 +67,7 @@ class UNetEngine:
     """Executes one model on one device.  `layers` is unet.py's topology."""
 
     def __init__(self, topo, params, model_channels, film, device, precision="f32", in_channels=2, planar=True,
-                 winograd=True):
+                 winograd=True, step_graph=False):
         """precision: "f32" = exact fp32 MFMA everywhere; "f16x3" = every conv evaluates
         each fp32 product as three f16 MFMAs (fp32-equivalent accuracy, see
         include/ddpm3d.h); "f16" = one f16 MFMA per product (the reference's --use_fp16);
@@ -74,6 +75,10 @@ class UNetEngine:
         if precision not in H.PRECISIONS:
             raise ValueError("precision must be one of %s" % sorted(H.PRECISIONS))
         self.precision = precision
+        # replay a captured hipGraph of the forward instead of issuing its launches one by one (_Plan._replay)
+        self.step_graph = step_graph
+        # A/B switch: combine split convs in a reduce launch of their own (DDPM3D_HINT_SPLITK_TWO_LAUNCH)
+        self.splitk_two_launch = os.environ.get("DDPM3D_SPLITK_TWO_LAUNCH", "0") == "1"
         self.lib = H.load()
         self.topo = topo
         self.device = device
@@ -247,6 +252,7 @@ class _Plan:
         self.bias_patches = []  # (conv desc, film offset): additive-embedding conv1 bias rows
         self.conv_meta = {}     # step index -> (kernel tag, algorithmic FLOPs)
         self.timing = None      # set to a list to collect (tag, flops, start_evt, end_evt) per conv
+        self.graphs = {}        # film-row mode -> (captured forward, its static input buffers): _replay()
         dev = eng.device
         topo = eng.topo
         lib = eng.lib
@@ -341,7 +347,9 @@ class _Plan:
         release(h)
         # one split-K scratch buffer shared by every conv of the plan (they run in stream order)
         if self.ws_bytes:
-            self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+            # zero once: its front holds the arrival counters of the in-launch split-K combine (ddpm3d.h), which
+            # every call leaves zero again
+            self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=dev)
             for dsc in self.ws_descs:
                 dsc.workspace, dsc.workspace_bytes = H.ptr(self.workspace), self.ws_bytes
 
@@ -390,13 +398,6 @@ class _Plan:
         if out is not None:
             d.N, d.D, d.H, d.W = N, out.D, out.H, out.W
             d.out = H.ptr(out.buf)
-            if want_stats:
-                out.rows = lib.ddpm3d_conv_stats_rows(N, out.D, out.H, out.W, cin_total, pc.Cout, pc.k,
-                                                      pc_use.precision)
-                out.stats = torch.empty(N * out.rows * pc.Cout * 2, dtype=torch.float64,
-                                        device=self.eng.device)     # fp64 (sum, sum of squares) rows
-                self.keep.append(out.stats)    # the descriptor holds a raw pointer
-                d.stats, d.stats_rows = H.ptr(out.stats), out.rows
         else:
             s = srcs[0]
             d.N, d.D, d.H, d.W = N, s.D, s.H, s.W
@@ -447,7 +448,16 @@ class _Plan:
             # read out of bounds
             raise RuntimeError("residual has %d channels, the conv writes %d" % (res.C, pc.Cout))
         d.res = H.ptr(res.buf) if res is not None else 0
-        need = lib.ddpm3d_conv_workspace_bytes(N, d.D, d.H, d.W, d.Cin, pc.Cout, pc.k, pc_use.precision)
+        if self.eng.splitk_two_launch:
+            d.kernel_hint |= H.HINT_SPLITK_TWO_LAUNCH      # A/B: the reduce launch of r01-r03
+        # how the library will run this descriptor: statistics rows, split-K scratch
+        rows, need, _, _ = H.conv_plan(d)
+        if out is not None and want_stats:
+            out.rows = rows
+            out.stats = torch.empty(N * rows * pc.Cout * 2, dtype=torch.float64,
+                                    device=self.eng.device)     # fp64 (sum, sum of squares) rows
+            self.keep.append(out.stats)    # the descriptor holds a raw pointer
+            d.stats, d.stats_rows = H.ptr(out.stats), rows
         if need:
             self.ws_descs.append(d)
             self.ws_bytes = max(self.ws_bytes, need)
@@ -589,22 +599,30 @@ class _Plan:
     # ---- execution -----------------------------------------------------------
     def run(self, x, low_res, film_rows, film_stride, out=None):
         H.require_device(x, "x")
-        st = H.stream()
         if self.eng.planar:
             H.require_device(low_res, "low_res")
-            self.first_desc.src0 = x.data_ptr()
-            self.first_desc.src1 = low_res.data_ptr()
-            self.absmax_args[0], self.absmax_args[1] = x.data_ptr(), low_res.data_ptr()
+        if self.eng.step_graph and self.timing is None:
+            return self._replay(x, low_res, film_rows, film_stride, out)
+        target = out if out is not None else self.out_buf
+        self._enqueue(x.data_ptr(), low_res.data_ptr() if self.eng.planar else 0, film_rows.data_ptr(), film_stride,
+                      target.data_ptr())
+        return target
+
+    def _enqueue(self, xptr, lrptr, fptr, film_stride, outptr):
+        """Patch the per-call pointers into the descriptors and enqueue every step on the current stream."""
+        st = H.stream()
+        if self.eng.planar:
+            self.first_desc.src0 = xptr
+            self.first_desc.src1 = lrptr
+            self.absmax_args[0], self.absmax_args[1] = xptr, lrptr
         else:
-            self.absmax_args[0] = self.pad_args[0] = x.data_ptr()
-        fptr = film_rows.data_ptr()
+            self.absmax_args[0] = self.pad_args[0] = xptr
         for a in self.film_patches:
             a[12], a[13] = fptr, film_stride
         for dsc, off in self.bias_patches:
             dsc.bias = fptr + 4 * off
             dsc.bias_stride_n = film_stride
-        target = out if out is not None else self.out_buf
-        self.last_desc.out = target.data_ptr()
+        self.last_desc.out = outptr
         if self.timing is None:
             for fn, args in self.steps:
                 args[-1] = st
@@ -626,6 +644,49 @@ class _Plan:
                 if meta is not None:
                     e1.record()
                     self.timing.append((meta[0], meta[1], e0, e1))
+
+    # ---- step graph ----------------------------------------------
+    def _replay(self, x, low_res, film_rows, film_stride, out):
+        """One hipGraph launch instead of ~230 kernel launches issued from Python (what the reference does as
+        ~600 ATen launches per step, gaussian_diffusion.py:522-535).  The C ABI only enqueues, so a forward is
+        captured once per (plan, film-row mode) on torch's capture stream; what changes from step to step -- x,
+        the conditioning volume, the step's film row -- is copied into buffers the graph was captured on (two or
+        three small device-to-device copies in front of the launch), and the result is the plan's own output
+        buffer.  Same kernels, same arguments, same order as the eager replay: bit-identical results."""
+        eng, N = self.eng, self.N
+        shared = film_stride == 0
+        g = self.graphs.get(shared)
+        if g is None:
+            ft = eng.film_total
+            st = {"x": torch.empty_like(x),
+                  "lr": torch.empty_like(low_res) if eng.planar else None,
+                  "film": torch.empty((1 if shared else N) * ft, dtype=torch.float32, device=x.device)}
+            args = (st["x"].data_ptr(), st["lr"].data_ptr() if eng.planar else 0, st["film"].data_ptr(),
+                    0 if shared else ft, self.out_buf.data_ptr())
+            self._stage_inputs(st, x, low_res, film_rows, film_stride)
+            self._enqueue(*args)                    # eager once: lazy per-kernel attributes, first-touch of every buffer
+            torch.cuda.current_stream().synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._enqueue(*args)
+            g = self.graphs[shared] = (graph, st)
+        graph, st = g
+        self._stage_inputs(st, x, low_res, film_rows, film_stride)
+        graph.replay()
         if out is not None:
+            out.copy_(self.out_buf)
             return out
         return self.out_buf
+
+    def _stage_inputs(self, st, x, low_res, film_rows, film_stride):
+        ft = self.eng.film_total
+        st["x"].copy_(x)
+        if st["lr"] is not None:
+            # (every call: a caller's temporary may come back at the same address with other contents, so there is
+            # no safe way to tell "the same conditioning volume" -- the copy is 1 MiB per 64^3 volume, ~3 us)
+            st["lr"].copy_(low_res)
+        flat = film_rows.reshape(-1)
+        if film_stride == 0:
+            st["film"].copy_(flat[:ft])
+        else:
+            st["film"].view(self.N, ft).copy_(torch.as_strided(flat, (self.N, ft), (film_stride, 1)))

@@ -233,6 +233,9 @@ class UNetModel_noatt(nn.Module):
         # product = three f16 MFMAs on hi/lo-split operands; error vs fp64 within 2x of
         # the exact path, tests/test_gpu_ops.py) or "f32" (exact fp32 MFMA, 2.4x slower)
         self.conv_precision = os.environ.get("DDPM3D_PRECISION", "f16x3")
+        # replay one captured hipGraph per forward instead of ~230 launches issued from Python (engine.py:
+        # _Plan._replay); same kernels and arguments, bit-identical results.  DDPM3D_STEP_GRAPH=0/1 overrides.
+        self.step_graph = os.environ.get("DDPM3D_STEP_GRAPH", "0") == "1"
 
     # ---- precision switches (unet.py:999-1013) -------------------------------
     def convert_to_fp16(self):
@@ -274,8 +277,9 @@ class UNetModel_noatt(nn.Module):
                 self._engine = UNetEngine(self.topology, params, self.model_channels,
                                           self.use_scale_shift_norm, p0.device, self.conv_precision,
                                           in_channels=self.in_channels, planar=self._planar(),
-                                          winograd=self.dims == 3)
+                                          winograd=self.dims == 3, step_graph=self.step_graph)
             self._engine_key = key
+        self._engine.step_graph = self.step_graph
         return self._engine
 
     PLANAR_INPUT = False   # SuperRes models: the first conv reads x and low_res as two planes

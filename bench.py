@@ -269,6 +269,9 @@ def main():
     ap.add_argument("--large-size", type=int, default=None, help="override the factory's large_size flag")
     ap.add_argument("--attention-resolutions", default=None,
                     help="override, e.g. '16' with --large-size 128 --size 128 = BASELINE config 5")
+    ap.add_argument("--step-graph", type=int, choices=[0, 1], default=None,
+                    help="replay a captured hipGraph per forward (1) or issue the launches one by one (0); "
+                         "default: the model's own setting")
     ap.add_argument("--sampler", choices=["ddpm", "ddim"], default="ddpm",
                     help="ddim: --ddpm-steps DDIM steps (timestep_respacing ddimN, eta 0)")
     args = ap.parse_args()
@@ -348,6 +351,8 @@ def main():
     respacing = ("ddim%d" % args.ddpm_steps) if args.sampler == "ddim" else str(args.ddpm_steps)
     model, diff, sd = build_model(arch, respacing, device)
     model.conv_precision = args.precision
+    if args.step_graph is not None:
+        model.step_graph = bool(args.step_graph)
     # roofline peak for the dominant kernel's arithmetic: fp32 MFMA; f16 MFMA / 3 (three f16
     # MFMAs per algorithmic fp32 product); f16 MFMA (one per product)
     peak = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0,
@@ -569,7 +574,8 @@ def main():
                                       arch["num_res_blocks"], overrides),
                        "parallelism": "independent volumes per rank (dp%d), all_gather of finished samples" % world,
                        "tflop_per_volume": round(flops_fwd * T / B / 1e12, 1),
-                       "conv_arithmetic": ARITH[args.precision][1]},
+                       "conv_arithmetic": ARITH[args.precision][1],
+                       "launch": "hipGraph replay per forward" if model.step_graph else "one launch per kernel from the host"},
             # ranks the collective library saw in an all_gather, and which library: "nccl" = RCCL over xGMI;
             # "gloo" = the one-GPU rehearsal through host memory.  rccl_ranks is set for RCCL runs only.
             "collective_ranks": collective_ranks,

@@ -119,7 +119,11 @@ typedef struct ddpm3d_conv_desc {
                                16-byte aligned, or NULL                               */
     /* scratch for split-K partial sums (low-resolution levels, where the voxel
      * tiles alone cannot fill 256 CUs); >= ddpm3d_conv_workspace_bytes(...) bytes,
-     * may be shared by all convs of a stream, NULL when that query returns 0 */
+     * may be shared by all convs of a stream, NULL when that query returns 0.
+     * ABI 12: the buffer must be ZERO when it is first handed to the library (hipMemset once, at allocation):
+     * its front holds the arrival counters of the in-launch combine -- the workgroups of a split conv leave their
+     * partial sums here and the last one to arrive at a tile adds them up (in split order) and writes the
+     * output, so a split conv is ONE launch; every call leaves the counters zero again. */
     void* workspace;
     size_t workspace_bytes;
     /* 0 = the library picks the workgroup order from the shape.  DDPM3D_HINT_* bits select among
@@ -169,7 +173,11 @@ enum {
     /* bits 16..21: force the split factor over Cin of a conv with Cout > 64 (measurement only: no statistics,
      * workspace sized by the caller as S * output bytes; 0 = the library's own choice) */
     DDPM3D_HINT_SPLITK_SHIFT = 16,
-    DDPM3D_HINT_SPLITK_MASK = 0x3F0000
+    DDPM3D_HINT_SPLITK_MASK = 0x3F0000,
+    /* combine the slabs of a split conv in a launch of its own (the form until ABI 11) instead of inside the conv
+     * launch: same additions in the same order, bit-identical output; the statistics rows are grouped differently
+     * (size them with ddpm3d_conv_plan on the same descriptor).  Tests and A/B measurements. */
+    DDPM3D_HINT_SPLITK_TWO_LAUNCH = 0x400
 };
 
 int ddpm3d_abi_version(void);
@@ -228,6 +236,10 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* desc, void* stream);
  * Validates like ddpm3d_conv3d (the split-K workspace excepted) and launches nothing: measurement
  * bookkeeping for callers that attribute time per family (ABI 12). */
 int ddpm3d_conv_kernel_family(const ddpm3d_conv_desc* desc, char* name, int name_len);
+/* How ddpm3d_conv3d will run THIS descriptor (kernel_hint included): statistics rows per sample, workspace bytes,
+ * the split factor over Cin and whether the slabs are combined inside the launch.  Any out pointer may be NULL.
+ * Validates like ddpm3d_conv_kernel_family; launches nothing (ABI 12). */
+int ddpm3d_conv_plan(const ddpm3d_conv_desc* desc, int* stats_rows, size_t* workspace_bytes, int* split, int* fused);
 
 /*
  * GroupNorm32 statistics -> affine coefficients (nn.py:93-100: 32 groups,

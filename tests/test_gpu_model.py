@@ -431,3 +431,31 @@ def test_superres_model_with_several_image_channels():
     assert rel_err_per_channel(out.cpu().numpy(), ref.numpy()) < 1e-4
     with pytest.raises(RuntimeError):
         model(x.cuda(), torch.tensor([11]).cuda(), low_res=lr[:, :, :2].cuda())
+
+
+def test_step_graph_replay_equals_eager_launches():
+    """the forward as ONE captured hipGraph (engine.py: _Plan._replay) against the same plan
+    issued launch by launch -- same kernels, same arguments: bitwise equal.  Covers the sampler's fast path
+    (one film row shared by the batch, the step's x and row copied into the captured buffers), the module
+    call with one timestep per sample (a film row per sample), a second conditioning volume through the same
+    graph, and a whole 10-step loop."""
+    model, diff = build(TINY, "10")
+    shape = (2, 1, 8, 16, 16)
+    x, lr = inputs(shape)
+    lr2 = torch.from_numpy(synth.synth_low_res(shape, seed=99))
+    t = torch.tensor([37, 999])
+    draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, 11, seed=10)]
+    res = {}
+    for graph in (False, True):
+        model.step_graph = graph
+        with torch.no_grad():
+            y = model(x.cuda(), t.cuda(), low_res=lr.cuda())
+            y2 = model(x.cuda(), t.cuda(), low_res=lr2.cuda())
+            y3 = model(x.cuda(), t.cuda(), low_res=lr.cuda())
+            s = diff.p_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr.cuda()}, step_noise=draws[1:])
+        res[graph] = (y.cpu(), y2.cpu(), y3.cpu(), s.cpu())
+    eng = model.engine()
+    assert eng.step_graph and any(pl.graphs for pl in eng.plans.values())      # the graph path really ran
+    for a, b in zip(res[False], res[True]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert torch.equal(res[True][0], res[True][2]) and not torch.equal(res[True][0], res[True][1])

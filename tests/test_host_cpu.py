@@ -55,13 +55,14 @@ def test_library_exports_every_declared_symbol():
     # 64x32x32 level: 128-voxel tiles (2x8x8)
     assert lib.ddpm3d_conv_stats_rows(1, 64, 32, 32, 128, 128, 3, 3) == 32 * 4 * 4
     assert lib.ddpm3d_conv_workspace_bytes(1, 64, 64, 64, 128, 128, 3, 3) == 0
-    # 64x4x4 level: 8 voxel tiles -> split over Cin; the reduce kernel's rows shrink from 16 to 4
-    # voxels on this level so that it still launches >= 1024 workgroups (256 rows x 2 quad blocks)
-    assert lib.ddpm3d_conv_stats_rows(1, 64, 4, 4, 512, 512, 3, 3) == 256
-    # eight samples of the same level: 8 x 64 rows x 2 quad blocks of 16 voxels already fill it
-    assert lib.ddpm3d_conv_stats_rows(8, 64, 4, 4, 512, 512, 3, 3) == 64
+    # 64x4x4 level: 8 voxel tiles -> split over Cin, combined INSIDE the launch by the last workgroup to arrive at
+    # a tile (r04): one statistics row per tile, as an unsplit launch writes them (the reduce launch of r01-r03
+    # wrote one row per 4 voxels here: 256)
+    assert lib.ddpm3d_conv_stats_rows(1, 64, 4, 4, 512, 512, 3, 3) == 8
+    assert lib.ddpm3d_conv_stats_rows(8, 64, 4, 4, 512, 512, 3, 3) == 8
+    # workspace = arrival counters (one word per (tile, 128-cout block), 256-byte multiple) + S whole output tensors
     ws = lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 512, 512, 3, 3)
-    assert ws > 0 and ws % (1024 * 512 * 4) == 0
+    assert ws > 0 and ws % (1024 * 512 * 4) == 256
 
 
 def test_split_rule_and_prepass_argument_checks_without_a_gpu():
@@ -76,10 +77,10 @@ def test_split_rule_and_prepass_argument_checks_without_a_gpu():
         out_bytes = D * H * W * co * 4
         for prec in ((3, 6, 0) if k == 3 else (1, 5, 0)):      # the rule is per arithmetic mode since ABI 12
             ws = lib.ddpm3d_conv_workspace_bytes(1, D, H, W, ci, co, k, prec)
-            assert ws % out_bytes == 0
+            assert ws % out_bytes in (0, 256, 512)         # + the in-launch combine's arrival counters
             S = ws // out_bytes
             assert S <= (16 if k == 3 else ci // 16), (D, H, W, ci, co, k, prec, S)
-    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 1024, 384, 3, 3) == 16 * 64 * 4 * 4 * 384 * 4
+    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 1024, 384, 3, 3) == 256 + 16 * 64 * 4 * 4 * 384 * 4
     assert lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 1024, 384, 3, 7) == 0      # unknown precision
     lib.ddpm3d_pool_act.restype = ctypes.c_int
     vp = ctypes.c_void_p

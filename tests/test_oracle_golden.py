@@ -125,6 +125,29 @@ def test_unet_forward_tiny(golden, tag, over, shape, t):
     assert rel_err(y, ref) < 1e-6, tag
 
 
+@pytest.mark.parametrize("tag,over,shape,t", [
+    ("tiny_attn", dict(large_size=32, attention_resolutions="8,4", num_head_channels=32),
+     (1, 1, 8, 32, 32), [10]),
+    ("tiny_midattn", dict(large_size=32, attention_resolutions="1000", num_head_channels=32,
+                          mid_attention=True), (1, 1, 4, 32, 32), [77]),
+])
+def test_query_blocked_attention_oracle_vs_reference(golden, monkeypatch, tag, over, shape, t):
+    """The oracle walks the attention's QUERY axis in blocks (it has to at BASELINE config 5's T = 32 768, where
+    the reference's materialised T x T matrix is 4.3 GB per head).  With a block smaller than T and not dividing
+    it (T = 128 and 512 here) it still reproduces the reference's own outputs: the blocked form is the pinned
+    one, and is what the full-size GPU tests of the attention kernel are compared with."""
+    monkeypatch.setattr(unet_ref, "ATTN_QUERY_BLOCK", 48)
+    cfg = unet_ref.sr_config(**dict(TINY, **over))
+    y = _run(cfg, shape, t)
+    assert rel_err(y, golden("unet_forward.npz")[tag]) < 1e-6, tag
+    # and the fp64 evaluation used as the bar of those tests agrees with the fp32 one to fp32 rounding
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn(2, 32, 200, generator=g) for _ in range(3))
+    a32 = unet_ref.qkv_attention(q, k, v, block=64)
+    a64 = unet_ref.qkv_attention(q, k, v, block=200, dtype=torch.float64)
+    assert rel_err(a32.numpy(), a64.numpy()) < 2e-6
+
+
 def test_unet_forward_published_arch(golden):
     cfg = unet_ref.sr_config(**PUBLISHED)
     y = _run(cfg, (1, 1, 8, 32, 32), [251])
@@ -283,3 +306,23 @@ def test_new_attention_order_oracle_vs_reference(golden, tag):
         a = sampler_ref.p_sample_loop(lambda xx, t, _: unet_ref.unet_forward(sd, cfg, xx, t, y=y), tmap, tb,
                                       draws[0], draws[1:], None)
     assert rel_err(a.numpy(), g[tag + "/ddpm"]) < 1e-5
+
+
+def test_oracle_first_step_of_config2_vs_reference(golden):
+    """tests/golden/sampler250_64.npz is the reference's own run of BASELINE config 2 (published architecture,
+    1x64^3, 250 steps).  The oracle reproduces its first reverse step (one full-size forward + p_sample update on
+    the injected noise): the fixture, the oracle and the GPU tests that use either all speak of the same run."""
+    g = golden("sampler250_64.npz")
+    cfg = unet_ref.sr_config(**PUBLISHED)
+    sd = _sd(cfg)
+    tmap, tb = schedule_ref.spaced_schedule(1000, "linear", "250")
+    shape = (1, 1, 64, 64, 64)
+    draws = [torch.from_numpy(a) for a in synth.synth_noise(shape, 2, seed=10)]
+    lr = torch.from_numpy(synth.synth_low_res(shape, seed=1234))
+    i = len(tmap) - 1
+    with torch.no_grad():
+        out = unet_ref.unet_forward(sd, cfg, draws[0], torch.full((1,), tmap[i], dtype=torch.long), lr)
+        mean, log_var, x0 = sampler_ref.mean_variance(tb, out, draws[0], i, True, False, True)
+        img = mean + torch.exp(0.5 * log_var) * draws[1]
+    assert rel_err(img.numpy(), g["after1"]) < 1e-5
+    assert abs(float(img.mean()) - g["trace"][0][0]) < 1e-6 and abs(float(x0.mean()) - g["trace"][0][1]) < 1e-6

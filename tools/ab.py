@@ -27,13 +27,15 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--libs", default=None, help="space-separated library paths relative to the repo root ('-' = in-tree)")
     ap.add_argument("--trees", default=None, help="space-separated tree directories relative to the repo root")
+    ap.add_argument("--flags", default=None, help="'|'-separated sets of extra forward_time.py flags, one variant each "
+                                                  "(e.g. '|--two-launch|--graph'; an empty set = the defaults)")
     ap.add_argument("--rounds", type=int, default=int(os.environ.get("ROUNDS", "2")))
     ap.add_argument("rest", nargs=argparse.REMAINDER)
     a = ap.parse_args()
-    if (a.libs is None) == (a.trees is None):
-        ap.error("give --libs or --trees")
+    if sum(x is not None for x in (a.libs, a.trees, a.flags)) != 1:
+        ap.error("give one of --libs, --trees, --flags")
     rest = a.rest[1:] if a.rest[:1] == ["--"] else a.rest
-    variants = (a.libs or a.trees).split()
+    variants = a.flags.split("|") if a.flags is not None else (a.libs or a.trees).split()
     out = os.path.join(ROOT, a.out) if not os.path.isabs(a.out) else a.out
     os.makedirs(os.path.dirname(out), exist_ok=True)
     rows, missing = collections.defaultdict(list), []
@@ -43,7 +45,10 @@ def main():
                 env = dict(os.environ)
                 env.pop("DDPM3D_LIB", None)
                 cwd = ROOT
-                if a.libs is not None:
+                extra = []
+                if a.flags is not None:
+                    extra = v.split()
+                elif a.libs is not None:
                     if v != "-":
                         env["DDPM3D_LIB"] = os.path.join(ROOT, v)
                         if not os.path.exists(env["DDPM3D_LIB"]):
@@ -53,7 +58,8 @@ def main():
                     cwd = os.path.join(ROOT, v)
                 fe.write("==== round %d %s\n" % (r, v))
                 fe.flush()
-                p = subprocess.run([sys.executable, os.path.join(cwd, "tools", "forward_time.py"), "--tag", v] + rest,
+                p = subprocess.run([sys.executable, os.path.join(cwd, "tools", "forward_time.py"), "--tag", v or "default"]
+                                   + extra + rest,
                                    cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=fe, text=True)
                 line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
                 if p.returncode != 0 or len(line) != 1:
@@ -67,11 +73,11 @@ def main():
             lines.append("MISSING round %d variant %s: %s (see %s.stderr)" % (r, v, why, os.path.basename(out)))
         for v in variants:
             rs = rows[v]
-            lines.append("%-44s ms/forward: %s" % (v, "  ".join("%.3f" % x["ms_per_forward"] for x in rs) or "-"))
+            lines.append("%-44s ms/forward: %s" % (v or "default", "  ".join("%.3f" % x["ms_per_forward"] for x in rs) or "-"))
         fams = sorted({k for rs in rows.values() for x in rs for k in x["families_ms"]})
         for f in fams:
             lines.append("  %-28s %s" % (f, "   ".join(
-                "%s %.3f" % (os.path.basename(os.path.dirname(v)) or v,
+                "%s %.3f" % (os.path.basename(os.path.dirname(v)) or v or "default",
                              sum(x["families_ms"].get(f, 0) for x in rows[v]) / max(1, len(rows[v]))) for v in variants)))
         counts = {v: len(rows[v]) for v in variants}
         if len(set(counts.values())) != 1:
