@@ -108,19 +108,15 @@ static int conv_prepare(const ddpm3d_conv_desc* d, ConvK& k, ConvCfg& c, int& ro
         return fail(DDPM3D_EINVAL, "conv3d: out_layout %d", d->out_layout);
 
     c = ddpm3d_conv_cfg(d->N, d->D, d->H, d->W, d->Cin, d->Cout, d->ksize, d->precision);
-    if (d->kernel_hint & (DDPM3D_HINT_SPLITK_MASK | DDPM3D_HINT_SPLITK_TWO_LAUNCH)) {
-        // tests and measurements (tools/splitk_sweep.py): force the split factor and / or the two-launch combine;
-        // the caller sizes statistics and workspace with ddpm3d_conv_plan on the same descriptor
-        int s_forced = (d->kernel_hint & DDPM3D_HINT_SPLITK_MASK) >> DDPM3D_HINT_SPLITK_SHIFT;
+    if (d->kernel_hint & DDPM3D_HINT_SPLITK_MASK) {
+        // measurements (tools/splitk_sweep.py): force the split factor; the caller sizes statistics and workspace
+        // with ddpm3d_conv_plan on the same descriptor
+        const int s_forced = (d->kernel_hint & DDPM3D_HINT_SPLITK_MASK) >> DDPM3D_HINT_SPLITK_SHIFT;
         const int nch = ddpm3d_cin_pad(d->Cin) / DDPM3D_CONV_CK;
-        if (s_forced == 0) s_forced = c.S;
         if (s_forced > nch || (s_forced != c.S && c.WN != 4))
             return fail(DDPM3D_EINVAL, "conv3d: a forced split factor needs Cout > 64 and S <= Cin / 16");
-        ddpm3d_conv_cfg_split(c, s_forced, !(d->kernel_hint & DDPM3D_HINT_SPLITK_TWO_LAUNCH), d->N, d->D, d->H, d->W, d->Cout);
+        ddpm3d_conv_cfg_split(c, s_forced, d->N, d->D, d->H, d->W, d->Cout);
     }
-    // (the exact mode's four-byte slab stores and the NCDHW edge keep the reduce launch)
-    if (c.fused && (d->out_layout != DDPM3D_OUT_NDHWC))
-        ddpm3d_conv_cfg_split(c, c.S, false, d->N, d->D, d->H, d->W, d->Cout);
     if (prec_wz(d->precision) &&
         !(wz_layer_ok(d->Cout, d->Cin, d->ksize) && c.WN == 4 && c.MT == 4 &&
           (d->in_mode == DDPM3D_IN_SAME || d->in_mode == DDPM3D_IN_UP)))
@@ -162,8 +158,7 @@ static int conv_prepare(const ddpm3d_conv_desc* d, ConvK& k, ConvCfg& c, int& ro
     k.chunks_per_split = (k.CinPad / DDPM3D_CONV_CK + c.S - 1) / c.S;
     // 1x1 convs: whole 32-channel blocks per split (conv1x1.hip walks K in those; any range suits the general kernel)
     if (d->ksize == 1 && c.S > 1) k.chunks_per_split = (k.chunks_per_split + 1) & ~1;
-    k.tickets = c.fused ? (unsigned*)d->workspace : nullptr;
-    k.partial = (float*)((char*)d->workspace + c.ticket_bytes);
+    k.partial = (float*)d->workspace;
     {
         // extents for the kernel's buffer descriptors (32-bit offsets)
         const bool dbl = d->in_mode == DDPM3D_IN_POOL || d->in_mode == DDPM3D_IN_STRIDE2;
@@ -216,11 +211,11 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* d, void* stream) {
         return launched(ddpm3d_launch_conv_skinny(k, d->precision, (hipStream_t)stream), "conv3d (skinny)");
     const int rc = route == ROUTE_PW ? launched(ddpm3d_launch_conv_pw(k, c, (hipStream_t)stream), "conv3d (1x1)")
                                      : launched(ddpm3d_launch_conv(k, c, (hipStream_t)stream), "conv3d");
-    if (rc != DDPM3D_OK || c.S == 1 || c.fused) return rc;
+    if (rc != DDPM3D_OK || c.S == 1) return rc;
     return launched(ddpm3d_launch_splitk_reduce(k, (hipStream_t)stream), "conv3d split-K reduce");
 }
 
-int ddpm3d_conv_plan(const ddpm3d_conv_desc* d, int* stats_rows, size_t* workspace_bytes, int* split, int* fused) {
+int ddpm3d_conv_plan(const ddpm3d_conv_desc* d, int* stats_rows, size_t* workspace_bytes, int* split) {
     ConvK k;
     ConvCfg c;
     int route = ROUTE_GENERAL;
@@ -229,7 +224,6 @@ int ddpm3d_conv_plan(const ddpm3d_conv_desc* d, int* stats_rows, size_t* workspa
     if (stats_rows) *stats_rows = c.stats_rows;
     if (workspace_bytes) *workspace_bytes = c.workspace_bytes;
     if (split) *split = c.S;
-    if (fused) *fused = c.fused;
     return DDPM3D_OK;
 }
 

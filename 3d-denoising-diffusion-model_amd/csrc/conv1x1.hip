@@ -216,12 +216,10 @@ __global__ __launch_bounds__(256, DDPM3D_PW_WGS) void conv3d_pw_kernel(const Con
     }
 
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    bool wt = true;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        wt &= conv_epilogue<PREC, 4, 1, TXL, TYL, WIDE>(p, acc[j], n, z0, y0, x0, tile_in_n, wave,
-                                                        wg.cy * 128 + j * 32 + (lane & 31), g, wg.split, asc.inv);
-    if (p.tickets != nullptr) splitk_finish<TXL, TYL>(p, lds, wt, n, z0, y0, x0, tile_in_n, wg.cy);
+        conv_epilogue<PREC, 4, 1, TXL, TYL, WIDE>(p, acc[j], n, z0, y0, x0, tile_in_n, wave,
+                                                  wg.cy * 128 + j * 32 + (lane & 31), g, wg.split, asc.inv);
 }
 
 template <int PREC, int S16, int TXL, int TYL>

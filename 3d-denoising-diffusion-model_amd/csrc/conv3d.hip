@@ -307,11 +307,8 @@ __global__ __launch_bounds__(256, (PIPEM == 2 ? 1 : (TXL == 2 ? 2 : 3))) void co
     if (!wave_active) return;
 
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
-    const bool wt = conv_epilogue<PREC, WM, MT, TXL, TYL, PREC == 2 || PREC == 5>(p, acc, n, z0, y0, x0, tile_in_n, wm, cout, half,
-                                                                                 wg.split, asc.inv);
-    // in-launch combine of a split launch (128-voxel x 128-cout workgroups only: every wave is active there)
-    if constexpr (WN == 4 && MT == 4)
-        if (p.tickets != nullptr) splitk_finish<TXL, TYL>(p, lds, wt, n, z0, y0, x0, tile_in_n, wg.cy);
+    conv_epilogue<PREC, WM, MT, TXL, TYL, PREC == 2 || PREC == 5>(p, acc, n, z0, y0, x0, tile_in_n, wm, cout, half, wg.split,
+                                                                 asc.inv);
 }
 
 // This file is compiled once per arithmetic mode (-DDDPM3D_PREC_ONLY=0|1|2|5, and 3 = the

@@ -68,13 +68,11 @@ __device__ __forceinline__ constexpr int epi_tz(int m) {
 }
 
 // KSPLIT: the caller knows this is a split launch (p.ksplit > 1): only the slab code is instantiated.
-// Returns true when every slab store of the lane's tile was a WRITE-THROUGH (sc1) store -- the 16-byte form on a
-// full tile -- so that splitk_finish (below) may signal without an agent-scope release.
 template <int PREC, int WM, int MT, int TXL, int TYL, bool WIDE = false, bool ZPAIRS = false, bool KSPLIT = false>
 // pre_ws / pre_bias (pre = true): p.wscale[cout] and the lane's bias, loaded by the caller at kernel
 // START (conv3d_wz.h): at the epilogue's start they are a dependent global load -- ~2k cycles at the
 // head of a phase in which the wave issues no MFMA
-__device__ __forceinline__ bool conv_epilogue(const ConvK& p, const f32x16 (&acc)[MT], int n, int z0, int y0,
+__device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc)[MT], int n, int z0, int y0,
                                               int x0, int tile_in_n, int wm, int cout, int half, int ksplit_idx,
                                               float inv_act, bool pre = false, float pre_ws = 1.0f,
                                               float pre_bias = 0.0f) {
@@ -193,17 +191,12 @@ __device__ __forceinline__ bool conv_epilogue(const ConvK& p, const f32x16 (&acc
                         const int m0 = (wm * MT + t) * 32 + 8 * g;
                         const int ty = (m0 >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m0), tx = m0 & (TX - 1);
                         const unsigned so = (unsigned)((tz * p.H + ty) * p.W + tx) * cstride;
-                        // raw slab: WRITE-THROUGH (aux 16 = sc1), the hand-off form of splitk_finish -- with the tile offset
-                        // in the VGPR and soffset 0.  Measured (r04, scratch/dbg_fused*.py -> profiles/r04_sc1_store_hazard.txt):
-                        // `buffer_store_dwordx4 ... sc1` with an SGPR soffset stores, now and then, the NEXT group's value in its
-                        // first data register (one wrong float per 16-cout run, in late workgroups of a launch, ~1e-4 of the
-                        // elements; never with plain stores, never with four-byte stores): hipcc inserts the wait state between a
-                        // > 8-byte store and the VALU that overwrites its data registers only when soffset is NOT a register
-                        // (the documented gfx9 exemption), and the exemption does not hold for the slower sc1 store.
+                        // raw slab of a split launch (the reduce launch reads it): plain 16-byte stores.  (Write-through
+                        // sc1 stores with an SGPR soffset lose a store-data wait state: profiles/r04_sc1_store_hazard.txt.)
                         if (split)
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]),
                                                                          __builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])},
-                                                                   drsrc, wv + so, 0, 16);
+                                                                   drsrc, wv, so, 0);
                         else if (KSPLIT) { }
                         else if (o16)
                             __builtin_amdgcn_raw_buffer_store_b64(u32x2{half_pack(a[0], a[1], f16), half_pack(a[2], a[3], f16)}, drsrc, wv, so, 0);
@@ -232,7 +225,7 @@ __device__ __forceinline__ bool conv_epilogue(const ConvK& p, const f32x16 (&acc
                             make_double2(s1, s2);
                     }
                 }
-                return split;
+                return;
             }
             roff_ = cvalid ? rbase : DDPM3D_OOB_OFFSET;
             const float bias = (!split && cvalid) ? (pre ? pre_bias : p.bias[(size_t)n * p.bias_stride_n + cout]) : 0.0f;
@@ -298,7 +291,7 @@ __device__ __forceinline__ bool conv_epilogue(const ConvK& p, const f32x16 (&acc
                         make_double2(s1, s2);
                 }
             }
-            return false;
+            return;
         }
     }
     if (KSPLIT || p.ksplit > 1) {
@@ -318,9 +311,9 @@ __device__ __forceinline__ bool conv_epilogue(const ConvK& p, const f32x16 (&acc
                         PREC != 0 ? acc[t][reg] * oscale : acc[t][reg];
             }
         }
-        return false;
+        return;
     }
-    if constexpr (KSPLIT) return false;
+    if constexpr (KSPLIT) return;
     const float bias = cvalid ? (pre ? pre_bias : p.bias[(size_t)n * p.bias_stride_n + cout]) : 0.0f;
     GnAcc gs;
     gs.init(0.0f);
@@ -360,117 +353,6 @@ __device__ __forceinline__ bool conv_epilogue(const ConvK& p, const f32x16 (&acc
                 make_double2(s1, s2);
         }
     }
-    return false;
 }
 
 
-// ---- split-K: combine INSIDE the launch (r04) --------------------------------------------------------------
-// The S workgroups of one (sample, tile, 128-cout block) each leave a raw slab (conv_epilogue above), then draw a
-// ticket; the one that draws S - 1 -- the last to arrive, whichever split it computed -- sums the S slabs of its
-// tile IN SLAB ORDER, adds bias and residual, stores the output and the tile's GroupNorm partial sums: what
-// conv_splitk_reduce_v4_kernel did in a launch of its own (same additions in the same order: the output is
-// bit-identical to the two-launch form's; the statistics are grouped per TILE instead of per reduce row, as an
-// unsplit launch groups them).  No workgroup waits for another: nothing can hang.
-//
-// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility / cdna_hip_programming.md, in-launch split-K):
-//   producer  slab stores write-through (sc1, `wt`) or plain + agent-scope release; every wave drains its stores
-//             (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane: [release,] relaxed agent-scope fetch_add;
-//   consumer  the wave whose add came last: agent-scope acquire (invalidates this CU's L1), s_waitcnt vmcnt(0),
-//             workgroup barrier, then plain loads by every wave.
-// The tickets (ConvK::tickets, one word per (n, tile, cout block)) are zero before the launch and the last
-// arriver puts its word back to zero: a later launch on the same workspace (stream order) finds them clean.
-// lds: the kernel's dynamic LDS (>= 8208 bytes, dead by now: the first barrier below is also its last reader's).
-template <int TXL, int TYL>
-__device__ __forceinline__ void splitk_finish(const ConvK& p, unsigned char* lds, bool wt, int n, int z0, int y0,
-                                              int x0, int tile_in_n, int cy) {
-    constexpr int TX = 1 << TXL, TY = 1 << TYL;
-    const int tid = threadIdx.x;
-    unsigned* flag = reinterpret_cast<unsigned*>(lds);
-    const unsigned group = ((unsigned)n * (unsigned)(p.tilesZ * p.tilesY * p.tilesX) + (unsigned)tile_in_n) *
-                               (unsigned)(p.CoutPad / 128) + (unsigned)cy;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        if (!wt) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        *flag = __hip_atomic_fetch_add(p.tickets + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (*flag != (unsigned)p.ksplit - 1u) return;
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(p.tickets + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-
-    // thread = (cout quad q of the block's 32, voxel lane vl of 8): a wave reads two voxels x 512 contiguous bytes
-    const int q = tid & 31, vl = tid >> 5;
-    const int c4 = cy * 128 + 4 * q;
-    const size_t DHW = (size_t)p.D * p.H * p.W;
-    const size_t slab_stride = (size_t)p.N * DHW * p.Cout;
-    const bool b16 = (p.io & DDPM3D_IO_OUT_BF16) != 0, f16 = (p.io & DDPM3D_IO_HALF_IS_F16) != 0;
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + (size_t)n * p.bias_stride_n + c4);
-    GnAcc gs[4];
-    float cnt = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) gs[c].init(0.0f);
-#pragma unroll 2
-    for (int k = 0; k < 16; ++k) {
-        const int i = vl + 8 * k;
-        const int z = z0 + (i >> (TXL + TYL)), y = y0 + ((i >> TXL) & (TY - 1)), x = x0 + (i & (TX - 1));
-        if (z < p.D && y < p.H && x < p.W) {
-            const size_t e = ((size_t)n * DHW + ((size_t)z * p.H + y) * p.W + x) * p.Cout + c4;
-            f32x4 val = *reinterpret_cast<const f32x4*>(p.partial + e);
-            int s = 1;
-            for (; s + 3 < p.ksplit; s += 4) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(p.partial + e + (size_t)s * slab_stride);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.partial + e + (size_t)(s + 1) * slab_stride);
-                const f32x4 c = *reinterpret_cast<const f32x4*>(p.partial + e + (size_t)(s + 2) * slab_stride);
-                const f32x4 d = *reinterpret_cast<const f32x4*>(p.partial + e + (size_t)(s + 3) * slab_stride);
-                val += a; val += b; val += c; val += d;
-            }
-            for (; s < p.ksplit; ++s) val += *reinterpret_cast<const f32x4*>(p.partial + e + (size_t)s * slab_stride);
-            val += bias;
-            if (p.res_mode != DDPM3D_RES_NONE) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) val[c] += ddpm3d_residual(p, n, z, y, x, c4 + c);
-            }
-            if (b16)
-                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + e) =
-                    u32x2{half_pack(val[0], val[1], f16), half_pack(val[2], val[3], f16)};
-            else
-                *reinterpret_cast<f32x4*>(p.out + e) = val;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (cnt == 0.0f) gs[c].init(val[c]);
-                gs[c].add(val[c]);
-            }
-            cnt += 1.0f;
-        }
-    }
-    if (p.stats != nullptr) {
-        // one row per tile (row = tile_in_n, as an unsplit launch of this tile grid writes them).  Fold in a fixed
-        // order: the two voxel lanes of a wave (lane, lane ^ 32), then the four waves through LDS.
-        double* red = reinterpret_cast<double*>(lds + 16);      // [4 waves][128 couts][2]
-        const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            double d1 = gs[c].sum1(cnt), d2 = gs[c].sum2(cnt);
-            const double o1 = __shfl_xor(d1, 32), o2 = __shfl_xor(d2, 32);
-            if (lane < 32) {
-                red[((wave * 128) + 4 * q + c) * 2] = d1 + o1;
-                red[((wave * 128) + 4 * q + c) * 2 + 1] = d2 + o2;
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const double a = (red[tid * 2] + red[(128 + tid) * 2]) + (red[(256 + tid) * 2] + red[(384 + tid) * 2]);
-            const double b = (red[tid * 2 + 1] + red[(128 + tid) * 2 + 1]) + (red[(256 + tid) * 2 + 1] + red[(384 + tid) * 2 + 1]);
-            *reinterpret_cast<double2*>(p.stats + (((size_t)n * p.Cout + cy * 128 + tid) * p.stats_rows + tile_in_n) * 2) =
-                make_double2(a, b);
-        }
-    }
-}

@@ -26,7 +26,6 @@ struct ConvK {
     float* out;
     double* stats;   // [N][Cout][stats_rows][2] fp64 (sum, sum of squares)
     float* partial;  // split-K slabs [ksplit][N*D*H*W][Cout], raw accumulators
-    unsigned* tickets;   // in-launch combine (splitk_finish): one arrival counter per (n, tile, 128-cout block), or NULL
     const float* wscale;  // split-f16 modes: per-cout 1 / weight scale
     const float* in_bound;    // ddpm3d_conv_desc.in_bound (split-f16 modes)
     int in_bound_count, in_bound_stride;
@@ -51,32 +50,25 @@ struct ConvCfg {
     int tilesX, tilesY, tilesZ;
     int stats_rows;           // rows per sample the executing path writes
     int reduce_vox;           // voxels per statistics row of the split-K reduce (16, 8 or 4)
-    size_t workspace_bytes;   // tickets + slabs needed when S > 1
-    int fused;                // S > 1 and the last workgroup to arrive at a tile combines the slabs (splitk_finish)
-    size_t ticket_bytes;      // arrival counters at the front of the workspace (fused only), 256-byte multiple
+    size_t workspace_bytes;   // slabs needed when S > 1
 };
 
 static inline int ddpm3d_round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int ddpm3d_cout_pad(int Cout) { return ddpm3d_round_up(Cout, 32); }
 static inline int ddpm3d_cin_pad(int Cin) { return ddpm3d_round_up(Cin, DDPM3D_CONV_CK); }
 
-// Fill the split-dependent fields for a split factor S (the rule's own, or a forced one) and the combine form.
-static inline void ddpm3d_conv_cfg_split(ConvCfg& c, int S, bool allow_fuse, int N, int D, int H, int W, int Cout) {
+// Fill the split-dependent fields for a split factor S (the rule's own, or a forced one).
+static inline void ddpm3d_conv_cfg_split(ConvCfg& c, int S, int N, int D, int H, int W, int Cout) {
     const long long vox = (long long)D * H * W;
-    const long long tiles = (long long)c.tilesZ * c.tilesY * c.tilesX;
     c.S = S;
-    // the in-launch combine works on whole 128-cout blocks of 128-voxel tiles (every split conv of the network)
-    c.fused = (S > 1 && allow_fuse && c.WN == 4 && c.MT == 4 && Cout % 128 == 0) ? 1 : 0;
-    c.ticket_bytes = c.fused ? (size_t)ddpm3d_round_up((int)(N * tiles * (Cout / 128)) * 4, 256) : 0;
     if (S > 1) {
-        c.stats_rows = c.fused ? (int)tiles : (int)((vox + c.reduce_vox - 1) / c.reduce_vox);
-        c.workspace_bytes = c.ticket_bytes + (size_t)S * N * vox * Cout * sizeof(float);
+        c.stats_rows = (int)((vox + c.reduce_vox - 1) / c.reduce_vox);
+        c.workspace_bytes = (size_t)S * N * vox * Cout * sizeof(float);
     } else {
-        c.stats_rows = (int)tiles * (4 / c.WN);
+        c.stats_rows = c.tilesZ * c.tilesY * c.tilesX * (4 / c.WN);
         c.workspace_bytes = 0;
     }
 }
-
 
 // One rule, used by the launcher, by ddpm3d_conv_stats_rows /
 // ddpm3d_conv_workspace_bytes and by the weight packer: how a conv of this
@@ -169,7 +161,7 @@ static inline ConvCfg ddpm3d_conv_cfg(int N, int D, int H, int W, int Cin, int C
     while (c.reduce_vox > 4 &&
            (long long)N * ((vox + c.reduce_vox - 1) / c.reduce_vox) * ((Cout / 4 + 63) / 64) < 1024)
         c.reduce_vox /= 2;
-    ddpm3d_conv_cfg_split(c, best, true, N, D, H, W, Cout);
+    ddpm3d_conv_cfg_split(c, best, N, D, H, W, Cout);
     return c;
 }
 

@@ -122,30 +122,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
 
     constexpr int L = X3 ? 1 : 0;   // index of the lo halves (unused slot 0 alias in the f16 form)
     constexpr int R = X3 ? 3 : 8;
-#ifndef DDPM3D_WZ_RING_AHEAD
-#define DDPM3D_WZ_RING_AHEAD 0
-#endif
-#if DDPM3D_WZ_RING_AHEAD
-    // the weight ring's first R - 1 taps of a chunk are requested BEFORE the chunk's staging (for chunk 0 here, for
-    // chunk c + 1 behind chunk c's last tap): their L2 round trip runs beside stage_write instead of in front of tap 0
-    unsigned woff = (unsigned)chunk_begin * wchunk_stride;
-    auto bump = [&]() {
-        woff += wtap_stride;
-        asm volatile("" : "+s"(woff));
-    };
-    u32x4 bq[R][X3 ? 2 : 1];
-    auto ring_start = [&](int chunk) {
-        woff = (unsigned)chunk * wchunk_stride;
-#pragma unroll
-        for (int s = 0; s < R - 1; ++s) {
-            bq[s][0] = buffer_load16(wrsrc, wlane, woff);
-            if (X3) bq[s][L] = buffer_load16(wrsrc, wlane, woff + wpart);
-            bump();
-        }
-    };
-    if (chunk_begin < chunk_end) ring_start(chunk_begin);
-#endif
-
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         const bool more = chunk + 1 < chunk_end;
         const unsigned char* bufc = lds;
@@ -164,7 +140,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         // A operands one tap ahead as below: two ahead -1.5 %, three -16 %).  The stream's byte
         // offset is one running scalar
         if constexpr (IL == 3 || IL == 4 || IL == 6) __builtin_amdgcn_s_setprio(1);
-#if !DDPM3D_WZ_RING_AHEAD
         unsigned woff = (unsigned)chunk * wchunk_stride;
         auto bump = [&]() {
             woff += wtap_stride;
@@ -177,7 +152,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
             if (X3) bq[s][L] = buffer_load16(wrsrc, wlane, woff + wpart);
             bump();
         }
-#endif
         h8 af[2][2][X3 ? 2 : 1];   // [slot][row tile][hi|lo]: A operands, read one tap ahead
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -257,9 +231,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
             }
         }
         if constexpr (IL == 3 || IL == 4 || IL == 6) __builtin_amdgcn_s_setprio(0);
-#if DDPM3D_WZ_RING_AHEAD
-        if (more) ring_start(chunk + 1);
-#endif
         WZ_STAMP(6 + (chunk - chunk_begin) * 5);
     }
     WZ_STAMP(42);
@@ -277,13 +248,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     #ifndef DDPM3D_WZ_WIDE_X3
 #define DDPM3D_WZ_WIDE_X3 0     // measurement: the 16-byte epilogue in the f16x3 form too
 #endif
-    // a split launch leaves raw slabs: the 16-byte write-through form in every mode (the f16x3 form keeps its
-    // four-byte stores for finished outputs, whose epilogue hides behind 3x the MFMA work: r03), then the
-    // in-launch combine (conv3d_epilogue.h: splitk_finish) where the launcher asked for it
+    // a split launch leaves raw slabs for the reduce launch: 16-byte stores in every mode (r04; the f16x3 form keeps
+    // its four-byte stores for finished outputs, whose epilogue hides behind 3x the MFMA work -- a split workgroup is
+    // two to eight chunks long and nothing hides its slab stores: profiles/r04_tree_ab_wide_slabs_prologue_*.txt)
     if (p.ksplit > 1) {
-        const bool wt = conv_epilogue<1, 1, 4, TXL, TYL, true, G::NZP != 1, true>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half,
-                                                                                 wg.split, asc.inv, true, pre_ws, pre_bias);
-        if (p.tickets != nullptr) splitk_finish<TXL, TYL>(p, lds, wt, n, z0, y0, x0, tile_in_n, wg.cy);
+        conv_epilogue<1, 1, 4, TXL, TYL, true, G::NZP != 1, true>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split,
+                                                                 asc.inv, true, pre_ws, pre_bias);
     } else
     conv_epilogue<1, 1, 4, TXL, TYL, MODE != WZ_F16X3 || DDPM3D_WZ_WIDE_X3, G::NZP != 1>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split,
                                                                  asc.inv, true, pre_ws, pre_bias);

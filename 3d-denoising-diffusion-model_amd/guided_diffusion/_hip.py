@@ -32,7 +32,6 @@ ABI_VERSION = 12
 # ddpm3d_conv_desc.kernel_hint bits (launch orders of identical arithmetic; tests and A/B measurements)
 HINT_WSTAT_OFF, HINT_WSTAT_ON = 0x100, 0x200
 HINT_SPLITK_SHIFT = 16      # bits 16..21: forced split factor (measurement only, tools/splitk_sweep.py)
-HINT_SPLITK_TWO_LAUNCH = 0x400   # combine a split conv's slabs in a reduce launch of its own (tests, A/B)
 HINT_WZ_ORDER_SHIFT = 12     # bits 12..14: tap issue order of the f16x3 Winograd-D kernel (A/B measurements)
 
 _fp = C.c_void_p
@@ -53,6 +52,33 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvWeights(C.Structure):
+    """struct ddpm3d_conv_weights"""
+    _fields_ = [("w_packed", _fp), ("w_packed_wz", _fp), ("bias", _fp), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("ksize", C.c_int32), ("precision", C.c_int32), ("precision_wz", C.c_int32)]
+
+
+class Layer(C.Structure):
+    """struct ddpm3d_layer"""
+    _fields_ = [("kind", C.c_int32), ("updown", C.c_int32), ("heads", C.c_int32), ("film_off", C.c_int32),
+                ("norm1_gamma", _fp), ("norm1_beta", _fp), ("norm2_gamma", _fp), ("norm2_beta", _fp),
+                ("conv1", ConvWeights), ("conv2", ConvWeights), ("skip", ConvWeights)]
+
+
+class UnetDesc(C.Structure):
+    """struct ddpm3d_unet_desc"""
+    _fields_ = [("n_layers", C.c_int32), ("layers", C.POINTER(Layer)),
+                ("n_input_blocks", C.c_int32), ("input_block_layers", C.POINTER(C.c_int32)),
+                ("n_middle_layers", C.c_int32),
+                ("n_output_blocks", C.c_int32), ("output_block_layers", C.POINTER(C.c_int32)),
+                ("first", ConvWeights), ("out_gamma", _fp), ("out_beta", _fp), ("out", ConvWeights),
+                ("film", C.c_int32), ("planar", C.c_int32), ("in_channels", C.c_int32), ("cin_pad", C.c_int32),
+                ("arithmetic", C.c_int32)]
+
+
+LAYER_RES, LAYER_ATTN, LAYER_DOWNCONV, LAYER_UPCONV = 1, 2, 3, 4
+UPDOWN = {None: 0, "down": 1, "up": 2}
+
 EXPORTS = {
     # name: (restype, argtypes)
     "ddpm3d_abi_version": (C.c_int, []),
@@ -63,8 +89,13 @@ EXPORTS = {
     "ddpm3d_conv_workspace_bytes": (C.c_size_t, [C.c_int] * 8),
     "ddpm3d_conv3d": (C.c_int, [C.POINTER(ConvDesc), _fp]),
     "ddpm3d_conv_kernel_family": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, C.c_int]),
-    "ddpm3d_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_int),
-                                   C.POINTER(C.c_int)]),
+    "ddpm3d_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "ddpm3d_unet_plan_bytes": (C.c_size_t, [C.POINTER(UnetDesc), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ddpm3d_unet_plan_create": (C.c_int, [C.POINTER(UnetDesc), C.c_int, C.c_int, C.c_int, C.c_int, _fp, C.c_size_t,
+                                          C.POINTER(_fp)]),
+    "ddpm3d_unet_forward": (C.c_int, [_fp, _fp, _fp, _fp, C.c_int, _fp, _fp]),
+    "ddpm3d_unet_plan_destroy": (None, [_fp]),
+    "ddpm3d_unet_last_error": (C.c_char_p, []),
     "ddpm3d_gn_finalize": (C.c_int, [_fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_double, C.c_float, _fp, _fp, _fp, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "ddpm3d_absmax": (C.c_int, [_fp, _fp, C.c_int, C.c_size_t, _fp, _fp]),
@@ -131,10 +162,10 @@ def check(rc):
 
 
 def conv_plan(desc):
-    """(stats rows, workspace bytes, split factor, combined inside the launch) of ddpm3d_conv3d on this descriptor"""
-    rows, ws, split, fused = C.c_int(0), C.c_size_t(0), C.c_int(0), C.c_int(0)
-    check(load().ddpm3d_conv_plan(C.byref(desc), C.byref(rows), C.byref(ws), C.byref(split), C.byref(fused)))
-    return rows.value, ws.value, split.value, bool(fused.value)
+    """(stats rows, workspace bytes, split factor over Cin) of ddpm3d_conv3d on this descriptor"""
+    rows, ws, split = C.c_int(0), C.c_size_t(0), C.c_int(0)
+    check(load().ddpm3d_conv_plan(C.byref(desc), C.byref(rows), C.byref(ws), C.byref(split)))
+    return rows.value, ws.value, split.value
 
 
 def stream():

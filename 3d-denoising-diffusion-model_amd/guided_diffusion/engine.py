@@ -21,7 +21,6 @@ for every step of the schedule.
 import collections
 import ctypes as C
 import math
-import os
 
 import torch
 
@@ -77,8 +76,11 @@ class UNetEngine:
         self.precision = precision
         # replay a captured hipGraph of the forward instead of issuing its launches one by one (_Plan._replay)
         self.step_graph = step_graph
-        # A/B switch: combine split convs in a reduce launch of their own (DDPM3D_HINT_SPLITK_TWO_LAUNCH)
-        self.splitk_two_launch = os.environ.get("DDPM3D_SPLITK_TWO_LAUNCH", "0") == "1"
+        # run forwards on the C-level plan (ddpm3d_unet_plan: the same launch list compiled by libddpm3d itself)
+        # instead of this module's Python one; the Python plan stays the one that is instrumented (bench.py)
+        self.native_plan = False
+        self.native_plans = collections.OrderedDict()
+        self._native_desc = None
         self.lib = H.load()
         self.topo = topo
         self.device = device
@@ -205,6 +207,86 @@ class UNetEngine:
             self.plans.move_to_end(key)
         return pl
 
+    # ------------------------------------------------------------ the C-level plan
+    def _conv_weights(self, pc):
+        w = H.ConvWeights()
+        if pc is not None:
+            w.w_packed, w.bias = H.ptr(pc.w), H.ptr(pc.b)
+            w.Cout, w.Cin, w.ksize, w.precision = pc.Cout, pc.Cin, pc.k, pc.precision
+            if pc.wz is not None:
+                w.w_packed_wz, w.precision_wz = H.ptr(pc.wz.w), pc.wz.precision
+        return w
+
+    def native_desc(self):
+        """struct ddpm3d_unet_desc of this model (built once; borrows the engine's packed weights and parameters)"""
+        if self._native_desc is not None:
+            return self._native_desc[0]
+        topo, p = self.topo, self.p
+        layers, keep = [], []
+
+        def one(e):
+            L = H.Layer()
+            L.updown, L.heads = H.UPDOWN[e.updown], e.heads
+            if e.kind == "res":
+                L.kind = H.LAYER_RES
+                L.film_off = self.film_off[e.prefix]
+                L.norm1_gamma, L.norm1_beta = H.ptr(p[e.prefix + ".in_layers.0.weight"]), H.ptr(p[e.prefix + ".in_layers.0.bias"])
+                L.norm2_gamma, L.norm2_beta = H.ptr(p[e.prefix + ".out_layers.0.weight"]), H.ptr(p[e.prefix + ".out_layers.0.bias"])
+                L.conv1 = self._conv_weights(self.conv[e.prefix + ".in_layers.2"])
+                L.conv2 = self._conv_weights(self.conv[e.prefix + ".out_layers.3"])
+                L.skip = self._conv_weights(self.conv.get(e.prefix + ".skip_connection"))
+            elif e.kind == "attn":
+                L.kind = H.LAYER_ATTN
+                L.norm1_gamma, L.norm1_beta = H.ptr(p[e.prefix + ".norm.weight"]), H.ptr(p[e.prefix + ".norm.bias"])
+                L.conv1 = self._conv_weights(self.conv[e.prefix + ".qkv"])
+                L.conv2 = self._conv_weights(self.conv[e.prefix + ".proj_out"])
+            elif e.kind == "downconv":
+                L.kind = H.LAYER_DOWNCONV
+                L.conv1 = self._conv_weights(self.conv[e.prefix + ".op"])
+            elif e.kind == "upconv":
+                L.kind = H.LAYER_UPCONV
+                L.conv1 = self._conv_weights(self.conv[e.prefix + ".conv"])
+            else:
+                raise ValueError(e.kind)
+            return L
+
+        in_sizes, out_sizes = [], []
+        for blk in topo.input[1:]:
+            in_sizes.append(len(blk))
+            layers += [one(e) for e in blk]
+        layers += [one(e) for e in topo.middle]
+        for blk in topo.output:
+            out_sizes.append(len(blk))
+            layers += [one(e) for e in blk]
+        arr = (H.Layer * len(layers))(*layers)
+        ins = (C.c_int32 * max(1, len(in_sizes)))(*in_sizes)
+        outs = (C.c_int32 * max(1, len(out_sizes)))(*out_sizes)
+        d = H.UnetDesc()
+        d.n_layers, d.layers = len(layers), arr
+        d.n_input_blocks, d.input_block_layers = len(in_sizes), ins
+        d.n_middle_layers = len(topo.middle)
+        d.n_output_blocks, d.output_block_layers = len(out_sizes), outs
+        d.first = self._conv_weights(self.conv[topo.input[0][0].prefix])
+        d.out_gamma, d.out_beta = H.ptr(p["out.0.weight"]), H.ptr(p["out.0.bias"])
+        d.out = self._conv_weights(self.conv["out.2"])
+        d.film, d.planar = int(self.film), int(self.planar)
+        d.in_channels, d.cin_pad = self.in_channels, self.cin_pad
+        d.arithmetic = H.PRECISIONS[self.precision]
+        self._native_desc = (d, arr, ins, outs)      # ctypes arrays stay alive with the engine
+        return d
+
+    def native(self, N, D, Hh, W):
+        key = (N, D, Hh, W)
+        pl = self.native_plans.get(key)
+        if pl is None:
+            while len(self.native_plans) >= self.MAX_PLANS:
+                self.native_plans.popitem(last=False)
+            pl = _NativePlan(self, N, D, Hh, W)
+            self.native_plans[key] = pl
+        else:
+            self.native_plans.move_to_end(key)
+        return pl
+
     def forward(self, x, low_res, film_rows, film_stride, out=None):
         """x, low_res: (N,1,D,H,W) device fp32.  film_rows: device tensor whose row n
         (stride film_stride floats; 0 = one row shared by the batch) holds the
@@ -219,6 +301,8 @@ class UNetEngine:
             # (a batch that cannot be addressed is refused while its plan is being built, at the first
             # conv whose tensors pass 4 GiB -- conv_step applies the C ABI's own rule -- or, failing
             # that, by the library with DDPM3D_E2BIG before anything is enqueued for that conv)
+            if self.native_plan:
+                return self.native(N, D, Hh, W).run(x, low_res, film_rows, film_stride, out)
             pl = self.plan(N, D, Hh, W)
             return pl.run(x, low_res, film_rows, film_stride, out)
         except H.Ddpm3dError as e:
@@ -242,7 +326,104 @@ class UNetEngine:
         return res
 
 
-class _Plan:
+class _PlanBase:
+    """What a plan offers the engine: run() = enqueue one forward (launch by launch, or as one captured graph)."""
+    timing = None
+
+    def run(self, x, low_res, film_rows, film_stride, out=None):
+        H.require_device(x, "x")
+        if self.eng.planar:
+            H.require_device(low_res, "low_res")
+        if self.eng.step_graph and self.timing is None:
+            return self._replay(x, low_res, film_rows, film_stride, out)
+        target = out if out is not None else self.out_buf
+        self._enqueue(x.data_ptr(), low_res.data_ptr() if self.eng.planar else 0, film_rows.data_ptr(), film_stride,
+                      target.data_ptr())
+        return target
+
+    # ---- step graph (SURVEY 8 f3) ----------------------------------------------
+    def _replay(self, x, low_res, film_rows, film_stride, out):
+        """One hipGraph launch instead of ~230 kernel launches issued from the host (what the reference does as
+        ~600 ATen launches per step, gaussian_diffusion.py:522-535).  The C ABI only enqueues, so a forward is
+        captured once per (plan, film-row mode) on torch's capture stream; what changes from step to step -- x,
+        the conditioning volume, the step's film row -- is copied into buffers the graph was captured on (two or
+        three small device-to-device copies in front of the launch), and the result is the plan's own output
+        buffer.  Same kernels, same arguments, same order as the eager replay: bit-identical results."""
+        eng, N = self.eng, self.N
+        shared = film_stride == 0
+        g = self.graphs.get(shared)
+        if g is None:
+            ft = eng.film_total
+            st = {"x": torch.empty_like(x),
+                  "lr": torch.empty_like(low_res) if eng.planar else None,
+                  "film": torch.empty((1 if shared else N) * ft, dtype=torch.float32, device=x.device)}
+            args = (st["x"].data_ptr(), st["lr"].data_ptr() if eng.planar else 0, st["film"].data_ptr(),
+                    0 if shared else ft, self.out_buf.data_ptr())
+            self._stage_inputs(st, x, low_res, film_rows, film_stride)
+            self._enqueue(*args)                    # eager once: lazy per-kernel attributes, first-touch of every buffer
+            torch.cuda.current_stream().synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._enqueue(*args)
+            g = self.graphs[shared] = (graph, st)
+        graph, st = g
+        self._stage_inputs(st, x, low_res, film_rows, film_stride)
+        graph.replay()
+        if out is not None:
+            out.copy_(self.out_buf)
+            return out
+        return self.out_buf
+
+    def _stage_inputs(self, st, x, low_res, film_rows, film_stride):
+        ft = self.eng.film_total
+        st["x"].copy_(x)
+        if st["lr"] is not None:
+            # (every call: a caller's temporary may come back at the same address with other contents, so there is
+            # no safe way to tell "the same conditioning volume" -- the copy is 1 MiB per 64^3 volume, ~3 us)
+            st["lr"].copy_(low_res)
+        flat = film_rows.reshape(-1)
+        if film_stride == 0:
+            st["film"].copy_(flat[:ft])
+        else:
+            st["film"].view(self.N, ft).copy_(torch.as_strided(flat, (self.N, ft), (film_stride, 1)))
+
+
+class _NativePlan(_PlanBase):
+    """The C-level plan (include/ddpm3d.h: ddpm3d_unet_plan): libddpm3d compiles the launch list itself, into one
+    arena this object owns.  Same calls in the same order as _Plan below: bit-identical results."""
+
+    def __init__(self, eng, N, D, Hh, W):
+        self.eng, self.N = eng, N
+        self.graphs = {}
+        lib, desc = eng.lib, eng.native_desc()
+        need = lib.ddpm3d_unet_plan_bytes(C.byref(desc), N, D, Hh, W)
+        if need == 0:
+            msg = lib.ddpm3d_unet_last_error().decode()
+            # (the sizing query has no status code: a tensor beyond 32-bit offsets is what makes the engine split a batch)
+            raise H.Ddpm3dError(H.E_2BIG if "4 GiB" in msg else H.E_INVAL, msg)
+        self.arena = torch.empty(need, dtype=torch.uint8, device=eng.device)
+        self.act_bytes = need
+        handle = C.c_void_p()
+        rc = lib.ddpm3d_unet_plan_create(C.byref(desc), N, D, Hh, W, H.ptr(self.arena), need, C.byref(handle))
+        if rc != 0:
+            raise H.Ddpm3dError(rc, lib.ddpm3d_unet_last_error().decode())
+        self.handle = handle
+        self.out_buf = torch.empty((N, eng.conv["out.2"].Cout, D, Hh, W), dtype=torch.float32, device=eng.device)
+
+    def _enqueue(self, xptr, lrptr, fptr, film_stride, outptr):
+        rc = self.eng.lib.ddpm3d_unet_forward(self.handle, xptr, lrptr, fptr, film_stride, outptr, H.stream())
+        if rc != 0:
+            raise H.Ddpm3dError(rc, self.eng.lib.ddpm3d_unet_last_error().decode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.eng.lib.ddpm3d_unet_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class _Plan(_PlanBase):
     def __init__(self, eng, N, D, Hh, W):
         self.eng = eng
         self.N = N
@@ -347,9 +528,7 @@ class _Plan:
         release(h)
         # one split-K scratch buffer shared by every conv of the plan (they run in stream order)
         if self.ws_bytes:
-            # zero once: its front holds the arrival counters of the in-launch split-K combine (ddpm3d.h), which
-            # every call leaves zero again
-            self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=dev)
+            self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
             for dsc in self.ws_descs:
                 dsc.workspace, dsc.workspace_bytes = H.ptr(self.workspace), self.ws_bytes
 
@@ -448,10 +627,8 @@ class _Plan:
             # read out of bounds
             raise RuntimeError("residual has %d channels, the conv writes %d" % (res.C, pc.Cout))
         d.res = H.ptr(res.buf) if res is not None else 0
-        if self.eng.splitk_two_launch:
-            d.kernel_hint |= H.HINT_SPLITK_TWO_LAUNCH      # A/B: the reduce launch of r01-r03
         # how the library will run this descriptor: statistics rows, split-K scratch
-        rows, need, _, _ = H.conv_plan(d)
+        rows, need, _ = H.conv_plan(d)
         if out is not None and want_stats:
             out.rows = rows
             out.stats = torch.empty(N * rows * pc.Cout * 2, dtype=torch.float64,
@@ -597,17 +774,6 @@ class _Plan:
         return y
 
     # ---- execution -----------------------------------------------------------
-    def run(self, x, low_res, film_rows, film_stride, out=None):
-        H.require_device(x, "x")
-        if self.eng.planar:
-            H.require_device(low_res, "low_res")
-        if self.eng.step_graph and self.timing is None:
-            return self._replay(x, low_res, film_rows, film_stride, out)
-        target = out if out is not None else self.out_buf
-        self._enqueue(x.data_ptr(), low_res.data_ptr() if self.eng.planar else 0, film_rows.data_ptr(), film_stride,
-                      target.data_ptr())
-        return target
-
     def _enqueue(self, xptr, lrptr, fptr, film_stride, outptr):
         """Patch the per-call pointers into the descriptors and enqueue every step on the current stream."""
         st = H.stream()
@@ -644,49 +810,3 @@ class _Plan:
                 if meta is not None:
                     e1.record()
                     self.timing.append((meta[0], meta[1], e0, e1))
-
-    # ---- step graph ----------------------------------------------
-    def _replay(self, x, low_res, film_rows, film_stride, out):
-        """One hipGraph launch instead of ~230 kernel launches issued from Python (what the reference does as
-        ~600 ATen launches per step, gaussian_diffusion.py:522-535).  The C ABI only enqueues, so a forward is
-        captured once per (plan, film-row mode) on torch's capture stream; what changes from step to step -- x,
-        the conditioning volume, the step's film row -- is copied into buffers the graph was captured on (two or
-        three small device-to-device copies in front of the launch), and the result is the plan's own output
-        buffer.  Same kernels, same arguments, same order as the eager replay: bit-identical results."""
-        eng, N = self.eng, self.N
-        shared = film_stride == 0
-        g = self.graphs.get(shared)
-        if g is None:
-            ft = eng.film_total
-            st = {"x": torch.empty_like(x),
-                  "lr": torch.empty_like(low_res) if eng.planar else None,
-                  "film": torch.empty((1 if shared else N) * ft, dtype=torch.float32, device=x.device)}
-            args = (st["x"].data_ptr(), st["lr"].data_ptr() if eng.planar else 0, st["film"].data_ptr(),
-                    0 if shared else ft, self.out_buf.data_ptr())
-            self._stage_inputs(st, x, low_res, film_rows, film_stride)
-            self._enqueue(*args)                    # eager once: lazy per-kernel attributes, first-touch of every buffer
-            torch.cuda.current_stream().synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._enqueue(*args)
-            g = self.graphs[shared] = (graph, st)
-        graph, st = g
-        self._stage_inputs(st, x, low_res, film_rows, film_stride)
-        graph.replay()
-        if out is not None:
-            out.copy_(self.out_buf)
-            return out
-        return self.out_buf
-
-    def _stage_inputs(self, st, x, low_res, film_rows, film_stride):
-        ft = self.eng.film_total
-        st["x"].copy_(x)
-        if st["lr"] is not None:
-            # (every call: a caller's temporary may come back at the same address with other contents, so there is
-            # no safe way to tell "the same conditioning volume" -- the copy is 1 MiB per 64^3 volume, ~3 us)
-            st["lr"].copy_(low_res)
-        flat = film_rows.reshape(-1)
-        if film_stride == 0:
-            st["film"].copy_(flat[:ft])
-        else:
-            st["film"].view(self.N, ft).copy_(torch.as_strided(flat, (self.N, ft), (film_stride, 1)))

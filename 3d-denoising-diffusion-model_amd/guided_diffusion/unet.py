@@ -236,6 +236,9 @@ class UNetModel_noatt(nn.Module):
         # replay one captured hipGraph per forward instead of ~230 launches issued from Python (engine.py:
         # _Plan._replay); same kernels and arguments, bit-identical results.  DDPM3D_STEP_GRAPH=0/1 overrides.
         self.step_graph = os.environ.get("DDPM3D_STEP_GRAPH", "0") == "1"
+        # run on the C-level launch plan (ddpm3d_unet_plan_create / ddpm3d_unet_forward) instead of engine.py's
+        # Python one: the same calls in the same order, bit-identical.  DDPM3D_NATIVE_PLAN=0/1 overrides.
+        self.native_plan = os.environ.get("DDPM3D_NATIVE_PLAN", "0") == "1"
 
     # ---- precision switches (unet.py:999-1013) -------------------------------
     def convert_to_fp16(self):
@@ -280,6 +283,7 @@ class UNetModel_noatt(nn.Module):
                                           winograd=self.dims == 3, step_graph=self.step_graph)
             self._engine_key = key
         self._engine.step_graph = self.step_graph
+        self._engine.native_plan = self.native_plan
         return self._engine
 
     PLANAR_INPUT = False   # SuperRes models: the first conv reads x and low_res as two planes

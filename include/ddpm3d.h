@@ -119,11 +119,7 @@ typedef struct ddpm3d_conv_desc {
                                16-byte aligned, or NULL                               */
     /* scratch for split-K partial sums (low-resolution levels, where the voxel
      * tiles alone cannot fill 256 CUs); >= ddpm3d_conv_workspace_bytes(...) bytes,
-     * may be shared by all convs of a stream, NULL when that query returns 0.
-     * ABI 12: the buffer must be ZERO when it is first handed to the library (hipMemset once, at allocation):
-     * its front holds the arrival counters of the in-launch combine -- the workgroups of a split conv leave their
-     * partial sums here and the last one to arrive at a tile adds them up (in split order) and writes the
-     * output, so a split conv is ONE launch; every call leaves the counters zero again. */
+     * may be shared by all convs of a stream, NULL when that query returns 0 */
     void* workspace;
     size_t workspace_bytes;
     /* 0 = the library picks the workgroup order from the shape.  DDPM3D_HINT_* bits select among
@@ -170,14 +166,10 @@ enum {
      * library picks by shape) */
     DDPM3D_HINT_WZ_ORDER_SHIFT = 12,
     DDPM3D_HINT_WZ_ORDER_MASK = 0x7000,
-    /* bits 16..21: force the split factor over Cin of a conv with Cout > 64 (measurement only: no statistics,
-     * workspace sized by the caller as S * output bytes; 0 = the library's own choice) */
+    /* bits 16..21: force the split factor over Cin of a conv with Cout > 64 (measurement only: size statistics
+     * and workspace with ddpm3d_conv_plan on the same descriptor; 0 = the library's own choice) */
     DDPM3D_HINT_SPLITK_SHIFT = 16,
-    DDPM3D_HINT_SPLITK_MASK = 0x3F0000,
-    /* combine the slabs of a split conv in a launch of its own (the form until ABI 11) instead of inside the conv
-     * launch: same additions in the same order, bit-identical output; the statistics rows are grouped differently
-     * (size them with ddpm3d_conv_plan on the same descriptor).  Tests and A/B measurements. */
-    DDPM3D_HINT_SPLITK_TWO_LAUNCH = 0x400
+    DDPM3D_HINT_SPLITK_MASK = 0x3F0000
 };
 
 int ddpm3d_abi_version(void);
@@ -236,10 +228,81 @@ int ddpm3d_conv3d(const ddpm3d_conv_desc* desc, void* stream);
  * Validates like ddpm3d_conv3d (the split-K workspace excepted) and launches nothing: measurement
  * bookkeeping for callers that attribute time per family (ABI 12). */
 int ddpm3d_conv_kernel_family(const ddpm3d_conv_desc* desc, char* name, int name_len);
-/* How ddpm3d_conv3d will run THIS descriptor (kernel_hint included): statistics rows per sample, workspace bytes,
- * the split factor over Cin and whether the slabs are combined inside the launch.  Any out pointer may be NULL.
- * Validates like ddpm3d_conv_kernel_family; launches nothing (ABI 12). */
-int ddpm3d_conv_plan(const ddpm3d_conv_desc* desc, int* stats_rows, size_t* workspace_bytes, int* split, int* fused);
+/* How ddpm3d_conv3d will run THIS descriptor (kernel_hint included): statistics rows per sample, workspace bytes
+ * and the split factor over Cin.  Any out pointer may be NULL.  Validates like ddpm3d_conv_kernel_family;
+ * launches nothing (ABI 12). */
+int ddpm3d_conv_plan(const ddpm3d_conv_desc* desc, int* stats_rows, size_t* workspace_bytes, int* split);
+
+/*
+ * ---- The whole network (ABI 12; SURVEY 8b's `unet_forward(handle, ...)` granularity) ----------------------------
+ * A UNet forward -- UNetModel[_noatt] / SuperResModel[_noatt].forward, unet.py:1015-1044, :687-716, :1687-1694;
+ * ResBlock :236-256, AttentionBlock :296-305, Downsample / Upsample :102-105, :129-136, TimestepEmbedSequential
+ * :72-78 -- compiled ONCE per (model, N, D, H, W) into a flat list of the per-op calls of this header, every
+ * intermediate buffer carved out of ONE caller-provided device arena, and replayed by ddpm3d_unet_forward: what the
+ * Python host's launch plan (guided_diffusion/engine.py) does, for hosts that are not Python.  Same calls, same
+ * arguments, same order: bit-identical to the Python plan.  The timestep path (timestep_embedding, time_embed, the
+ * fused emb_layers Linear: "film rows") stays with the caller, who evaluates it for all steps of a schedule at once.
+ *
+ * The description borrows every pointer (packed weights, biases, GroupNorm parameters: device memory that must
+ * outlive the plan); layers are listed in execution order.
+ */
+typedef struct ddpm3d_conv_weights {
+    const void* w_packed;      /* ddpm3d_pack_conv_weight image in `precision`; NULL = layer absent             */
+    const void* w_packed_wz;   /* the Winograd-D image of the same layer (`precision_wz`), or NULL               */
+    const float* bias;         /* [Cout]                                                                         */
+    int32_t Cout, Cin, ksize;
+    int32_t precision, precision_wz;
+} ddpm3d_conv_weights;
+
+enum { DDPM3D_LAYER_RES = 1, DDPM3D_LAYER_ATTN = 2, DDPM3D_LAYER_DOWNCONV = 3, DDPM3D_LAYER_UPCONV = 4 };
+enum { DDPM3D_UPDOWN_NONE = 0, DDPM3D_UPDOWN_DOWN = 1, DDPM3D_UPDOWN_UP = 2 };
+
+typedef struct ddpm3d_layer {
+    int32_t kind;              /* DDPM3D_LAYER_*                                                                 */
+    int32_t updown;            /* ResBlock(down=True / up=True), unet.py:187-197                                 */
+    int32_t heads;             /* attention heads                                                                */
+    int32_t film_off;          /* ResBlock: offset of its emb_layers output inside a film row                    */
+    const float* norm1_gamma;  /* ResBlock in_layers.0 / AttentionBlock norm                                     */
+    const float* norm1_beta;
+    const float* norm2_gamma;  /* ResBlock out_layers.0                                                          */
+    const float* norm2_beta;
+    ddpm3d_conv_weights conv1; /* ResBlock in_layers.2 / attention qkv / Downsample op / Upsample conv           */
+    ddpm3d_conv_weights conv2; /* ResBlock out_layers.3 / attention proj_out                                     */
+    ddpm3d_conv_weights skip;  /* ResBlock skip_connection (w_packed NULL = Identity)                            */
+} ddpm3d_layer;
+
+typedef struct ddpm3d_unet_desc {
+    int32_t n_layers;
+    const ddpm3d_layer* layers;              /* input blocks 1.., middle block, output blocks, in execution order */
+    int32_t n_input_blocks;                  /* input blocks AFTER block 0 (the first conv)                       */
+    const int32_t* input_block_layers;       /* layers per input block                                            */
+    int32_t n_middle_layers;
+    int32_t n_output_blocks;
+    const int32_t* output_block_layers;
+    ddpm3d_conv_weights first;               /* input_blocks.0.0                                                  */
+    const float* out_gamma;                  /* out.0                                                             */
+    const float* out_beta;
+    ddpm3d_conv_weights out;                 /* out.2 (stored NCDHW)                                              */
+    int32_t film;                            /* use_scale_shift_norm (unet.py:248-255)                            */
+    int32_t planar;                          /* the first conv reads x and low_res as two planes (SuperRes)       */
+    int32_t in_channels, cin_pad;            /* otherwise: (N, in_channels, voxels) input, padded to cin_pad      */
+    int32_t arithmetic;                      /* DDPM3D_PREC_F32 / _F16X3 / _F16 / _BF16: which convs need input
+                                                bounds, and whether the residual stream is stored in 16 bits      */
+} ddpm3d_unet_desc;
+
+typedef struct ddpm3d_unet_plan ddpm3d_unet_plan;
+/* bytes of device arena a plan of this model and shape needs (0 = refused: ddpm3d_unet_last_error) */
+size_t ddpm3d_unet_plan_bytes(const ddpm3d_unet_desc* model, int N, int D, int H, int W);
+/* arena: 256-byte aligned device memory of at least that size, owned by the caller, private to the plan */
+int ddpm3d_unet_plan_create(const ddpm3d_unet_desc* model, int N, int D, int H, int W, void* arena, size_t arena_bytes,
+                            ddpm3d_unet_plan** plan);
+/* x (and low_res when planar): (N, 1 or in_channels, D, H, W) fp32; film_rows: row n at film_rows + n * film_stride
+ * (0 = one row for the batch) holds the fused emb_layers output of sample n's timestep; out: (N, Cout, D, H, W).
+ * Enqueue-only, like every call it is made of; one forward of a plan at a time. */
+int ddpm3d_unet_forward(ddpm3d_unet_plan* plan, const float* x, const float* low_res, const float* film_rows,
+                        int film_stride, float* out, void* stream);
+void ddpm3d_unet_plan_destroy(ddpm3d_unet_plan* plan);
+const char* ddpm3d_unet_last_error(void);
 
 /*
  * GroupNorm32 statistics -> affine coefficients (nn.py:93-100: 32 groups,

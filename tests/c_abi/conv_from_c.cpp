@@ -73,10 +73,7 @@ int main(void) {
     if (ddpm3d_conv_workspace_bytes(N, D, H, W, Ci, Co, 3, DDPM3D_PREC_F32) > ws_bytes)
         ws_bytes = ddpm3d_conv_workspace_bytes(N, D, H, W, Ci, Co, 3, DDPM3D_PREC_F32);
     void* dws = NULL;
-    if (ws_bytes) {
-        CHECK_HIP(hipMalloc(&dws, ws_bytes));
-        CHECK_HIP(hipMemset(dws, 0, ws_bytes));   /* once: the front holds the split-K arrival counters (ddpm3d.h) */
-    }
+    if (ws_bytes) CHECK_HIP(hipMalloc(&dws, ws_bytes));
     hipStream_t st;
     CHECK_HIP(hipStreamCreate(&st));
 

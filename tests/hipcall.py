@@ -88,18 +88,15 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
     else:
         out = torch.full((N, co, D, Hh, W), float("nan"), dtype=torch.float32, device=dev)
     d.out, d.out_layout = H.ptr(out), out_layout
-    # how the library will run THIS descriptor (hints included): statistics rows, scratch, split, combine form
-    rows, need, split, fused = H.conv_plan(d)
+    # how the library will run THIS descriptor (hints included): statistics rows, scratch, split over Cin
+    rows, need, split = H.conv_plan(d)
     if not hint and not planar:
         assert rows == lib.ddpm3d_conv_stats_rows(N, D, Hh, W, ci, co, k, d.precision)
         assert need == lib.ddpm3d_conv_workspace_bytes(N, D, Hh, W, ci, co, k, d.precision)
-    # the workspace starts out zero (ddpm3d.h): its front holds the arrival counters of the in-launch combine;
-    # the slabs behind them are poisoned so that a slab that was never written shows up as NaN
-    ws = torch.zeros(max(need, 16), dtype=torch.uint8, device=dev)
-    tick = need - split * N * D * Hh * W * co * 4 if need else 0
-    assert 0 <= tick < 1 << 20 and (tick > 0) == fused
+    assert need == (split * N * D * Hh * W * co * 4 if split > 1 else 0)
+    # the slabs start out poisoned: one that was never written shows up as NaN in the output
+    ws = torch.full((max(need, 16) // 4,), POISON, dtype=torch.float32, device=dev)
     if need:
-        ws[tick:].view(torch.float32).fill_(POISON)
         d.workspace, d.workspace_bytes = H.ptr(ws), need
     stats = None
     if want_stats and out_layout == H.OUT_NDHWC:
@@ -107,13 +104,11 @@ def conv3d(srcs, w, b, out_dhw, in_mode=H.IN_SAME, aff=None, act=H.ACT_NONE, res
         d.stats, d.stats_rows = H.ptr(stats), rows
     H.check(lib.ddpm3d_conv3d(C.byref(d), H.stream()))
     torch.cuda.synchronize()
-    if tick:
-        assert not ws[:tick].any(), "the arrival counters must be back to zero after the launch"
-    LAST_PLAN.update(split=split, fused=fused, rows=rows, ws=ws if need else None, ticket_bytes=tick)
+    LAST_PLAN.update(split=split, rows=rows)
     return out, stats, rows
 
 
-POISON = float("nan")   # what the slab area of a split conv's workspace holds before the launch
+POISON = float("nan")   # what a split conv's workspace holds before the launch
 LAST_PLAN = {}     # what the last conv3d() call ran as (tests assert that a path was really taken)
 
 

@@ -459,3 +459,84 @@ def test_step_graph_replay_equals_eager_launches():
     for a, b in zip(res[False], res[True]):
         assert torch.isfinite(a).all() and torch.equal(a, b)
     assert torch.equal(res[True][0], res[True][2]) and not torch.equal(res[True][0], res[True][1])
+
+
+@pytest.mark.parametrize("tag,over,shape,t,precision", [
+    ("tiny", {}, (2, 1, 8, 16, 16), [37, 999], "f16x3"),
+    ("tiny exact", {}, (1, 1, 5, 48, 16), [3], "f32"),
+    ("tiny additive", dict(use_scale_shift_norm=False), (1, 1, 4, 16, 16), [5], "f16x3"),
+    ("tiny conv resample", dict(resblock_updown=False), (1, 1, 4, 16, 16), [5], "f16x3"),
+    ("tiny attention", dict(large_size=32, attention_resolutions="8,4", num_head_channels=32), (1, 1, 8, 32, 32), [10], "f16x3"),
+    ("tiny bf16", {}, (1, 1, 8, 16, 16), [500], "bf16"),
+    ("tiny f16", {}, (1, 1, 8, 16, 16), [500], "f16"),
+    ("published", None, (1, 1, 8, 32, 32), [251], "f16x3"),
+])
+def test_native_plan_equals_python_plan(tag, over, shape, t, precision):
+    """The whole-network level of the C ABI (ddpm3d_unet_plan_create / ddpm3d_unet_forward: libddpm3d compiles the
+    launch list itself, into one caller-provided arena -- SURVEY 8b's `unet_forward(handle, ...)`) against the
+    Python host's plan of the same model: the same per-op calls in the same order, so the outputs are BITWISE
+    equal, per architecture variant and arithmetic; also through the sampler's fast path (one film row shared
+    by the batch), with the step graph on top, and for a second shape of the same model."""
+    model, diff = build(PUBLISHED if over is None else dict(TINY, **over), "10", precision=precision)
+    x, lr = inputs(shape)
+    tt = torch.tensor(t[:shape[0]])
+    res = {}
+    for native in (False, True):
+        model.native_plan = native
+        with torch.no_grad():
+            y = model(x.cuda(), tt.cuda(), low_res=lr.cuda())
+            draws = [torch.from_numpy(a).cuda() for a in synth.synth_noise(shape, 4, seed=10)]
+            it = diff.p_sample_loop_progressive(model, shape, draws[0], model_kwargs={"low_res": lr.cuda()},
+                                                step_noise=draws[1:] + draws[1:] * 4)
+            s = [next(it)["sample"].clone() for _ in range(3)]
+        res[native] = [y.cpu()] + [v.cpu() for v in s]
+    eng = model.engine()
+    assert eng.native_plan and eng.native_plans                      # the C-level plan really ran
+    for a, b in zip(res[False], res[True]):
+        assert torch.isfinite(a).all() and torch.equal(a, b), tag
+    # a captured graph of the C-level forward, and another shape through the same description
+    model.step_graph = True
+    with torch.no_grad():
+        yg = model(x.cuda(), tt.cuda(), low_res=lr.cuda())
+    assert torch.equal(yg.cpu(), res[True][0])
+    model.step_graph = False
+    shape2 = (1, 1, 4, 16, 16)
+    x2, lr2 = inputs(shape2)
+    with torch.no_grad():
+        a = model(x2.cuda(), tt[:1].cuda(), low_res=lr2.cuda())
+        model.native_plan = False
+        b = model(x2.cuda(), tt[:1].cuda(), low_res=lr2.cuda())
+    assert torch.equal(a, b)
+
+
+def test_native_plan_runs_the_2d_network_and_refuses_bad_arenas():
+    """create_model_and_diffusion's 2-D RGB network (ordinary multi-channel input, padded at the edge) through the
+    C-level plan, bitwise equal to the Python plan; and the C entry points refuse a NULL / undersized arena."""
+    import ctypes as C
+    import guided_diffusion._hip as H
+    from guided_diffusion import script_util as su
+    fl = su.model_and_diffusion_defaults()
+    fl.update(image_size=64, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", num_head_channels=32,
+              attention_resolutions="16", learn_sigma=True, use_scale_shift_norm=True, timestep_respacing="6")
+    model, _ = su.create_model_and_diffusion(**fl)
+    sd = model.state_dict()
+    model.load_state_dict({k: torch.from_numpy(synth.synth_param(k, tuple(v.shape))) for k, v in sd.items()})
+    model.to("cuda").eval()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 32, 48, generator=g).cuda()
+    t = torch.tensor([5, 700]).cuda()
+    with torch.no_grad():
+        a = model(x, t)
+        model.native_plan = True
+        b = model(x, t)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    eng = model.engine()
+    lib, desc = eng.lib, eng.native_desc()
+    need = lib.ddpm3d_unet_plan_bytes(C.byref(desc), 1, 1, 32, 48)
+    assert need > 0
+    handle = C.c_void_p()
+    small = torch.empty(need // 2, dtype=torch.uint8, device="cuda")
+    assert lib.ddpm3d_unet_plan_create(C.byref(desc), 1, 1, 32, 48, H.ptr(small), need // 2, C.byref(handle)) == H.E_INVAL
+    assert b"the plan needs" in lib.ddpm3d_unet_last_error()
+    assert lib.ddpm3d_unet_plan_create(C.byref(desc), 1, 1, 32, 48, 0, need, C.byref(handle)) == H.E_INVAL
+    assert lib.ddpm3d_unet_plan_bytes(C.byref(desc), 0, 1, 32, 48) == 0

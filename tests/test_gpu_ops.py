@@ -810,21 +810,20 @@ def test_conv3d_launch_orders_agree_bitwise(hc):
     (1, 24, 4, 4, 384, 384, 3, 3, 0, "none"),       # three cout blocks
     (1, 8, 8, 8, 256, 256, 3, 3, 0, "same"),        # 8x4x4 tiles (H % 8 == 0, D % 4 == 0)
     (2, 6, 8, 16, 128, 256, 3, 3, 3, "same"),       # 8x8x2 tiles (D % 4 != 0), batch 2, forced 3-way
-    (1, 5, 9, 11, 64, 128, 3, 3, 2, "same"),        # ragged tiles: four-byte slab stores behind a release fence
+    (1, 5, 9, 11, 64, 128, 3, 3, 2, "same"),        # ragged tiles: the general slab stores
     (1, 16, 4, 4, 128, 128, 3, 1, 0, "same"),       # direct f16x3 kernel on 4x4 tiles
-    (1, 9, 8, 8, 96, 128, 3, 0, 2, "same"),         # exact fp32 mode: four-byte slabs, release fence
+    (1, 9, 8, 8, 96, 128, 3, 0, 2, "same"),         # exact fp32 mode
     (1, 12, 4, 4, 256, 128, 3, 6, 0, "same"),       # bf16 Winograd form
+    (1, 64, 8, 8, 256, 384, 3, 3, 0, "same"),       # 768 workgroups: more than are resident at once
     (1, 16, 4, 4, 1024, 512, 1, 1, 0, "none"),      # the 1x1 skip-connection kernel, f16x3
     (1, 16, 8, 8, 768, 256, 1, 5, 4, "none"),       # ... bf16, forced 4-way
 ])
-def test_conv3d_splitk_in_launch_combine_equals_reduce_launch(hc, case):
-    """r04: the workgroup that arrives LAST at a tile of a split conv sums the slabs, in split
-    order, inside the conv launch (conv3d_epilogue.h: splitk_finish) -- no reduce launch.  Against the two-launch
-    form (DDPM3D_HINT_SPLITK_TWO_LAUNCH: the reduce kernel of r01-r03) on the same descriptor: the output is
-    BIT-identical (same additions in the same order), the GroupNorm partial sums agree to fp64 rounding of
-    differently grouped rows (one row per tile instead of one per reduce row), repeated launches are bitwise
-    repeatable although the last arriver differs from run to run, and the arrival counters are zero again after
-    every launch (hipcall.conv3d asserts it).  Also against torch on the CPU."""
+def test_conv3d_splitk_slabs_in_every_kernel_family(hc, case):
+    """Split-over-Cin launches of every kernel family (r04: their raw slabs leave the f16x3 Winograd kernel through
+    the 16-byte epilogue too; forced split factors may now carry statistics, sized by ddpm3d_conv_plan): against
+    torch on the CPU, with statistics, bitwise repeatable, no slab element left unwritten (the workspace starts
+    out as NaN).  (The in-launch combine of r04 -- last workgroup to arrive sums the slabs -- measured 7-12 % SLOWER
+    per forward than this reduce launch and is not in the product: profiles/r04_ab_splitk_in_launch_*.txt.)"""
     import guided_diffusion._hip as H
     N, D, Hh, W, ci, co, k, precision, forced, resm = case
     x = rnd(N, ci, D, Hh, W, seed=3)
@@ -845,53 +844,20 @@ def test_conv3d_splitk_in_launch_combine_equals_reduce_launch(hc, case):
     hint = forced << H.HINT_SPLITK_SHIFT
     xd, wd, bd = hc.to_ndhwc(x).cuda(), w.cuda(), b.cuda()
     out, stats, rows = hc.conv3d([xd], wd, bd, (D, Hh, W), hint=hint, **kw)
-    plan = dict(hc.LAST_PLAN)
-    assert plan["fused"] and plan["split"] > 1, plan          # the in-launch combine really ran
-    out2, stats2, rows2 = hc.conv3d([xd], wd, bd, (D, Hh, W), hint=hint | H.HINT_SPLITK_TWO_LAUNCH, **kw)
-    assert not hc.LAST_PLAN["fused"] and hc.LAST_PLAN["split"] == plan["split"]
+    assert hc.LAST_PLAN["split"] > 1 and (not forced or hc.LAST_PLAN["split"] == forced)
     o = out.cpu().numpy()
     assert np.isfinite(o).all()
-    assert np.array_equal(o, out2.cpu().numpy())
     tol = {0: 2e-5, 1: 2e-5, 3: 2e-5}.get(precision, 4e-3)
     assert rel_err(hc.to_ncdhw(out.cpu()).numpy(), ref.numpy()) < tol
     if stats is not None:
-        assert rows != rows2                                   # per tile vs per reduce row
-        a, c = stats.sum(dim=2).cpu().numpy(), stats2.sum(dim=2).cpu().numpy()
-        assert np.allclose(a, c, rtol=1e-6, atol=1e-6 * np.abs(c).max())
-        check_stats(stats, ref)
-    for _ in range(4):                                          # another last arriver, the same bits
+        # the sums are of the values the kernel stored: against the CPU result in the fp32-grade modes, against the
+        # kernel's own output in the 16-bit-operand modes
+        check_stats(stats, ref if precision in (0, 1, 3) else hc.to_ncdhw(out.cpu().float()))
+    for _ in range(3):
         o3, s3, _ = hc.conv3d([xd], wd, bd, (D, Hh, W), hint=hint, **kw)
         assert np.array_equal(o3.cpu().numpy(), o)
         if stats is not None:
             assert torch.equal(s3, stats)
-
-
-def test_conv3d_splitk_combine_through_16bit_tensors_and_pooled_residual(hc):
-    """The in-launch combine with what else the network hands a split conv: f16 / bf16 storage of the output and
-    the residual (rounded once, after the sum) and the pooled residual of a down ResBlock (RES_POOL), each
-    bitwise equal to the two-launch form."""
-    import guided_diffusion._hip as H
-    N, D, Hh, W, ci, co = 1, 16, 4, 4, 256, 128
-    x = hc.to_ndhwc(rnd(N, ci, D, Hh, W, seed=13)).cuda()
-    w, b = rnd(co, ci, 3, 3, 3, seed=14, scale=0.03).cuda(), rnd(co, seed=15).cuda()
-    for res_shape, mode, kw in [((N, co, D, Hh, W), H.RES_SAME, dict(out_f16=True)),
-                                ((N, co, D, Hh, W), H.RES_SAME, dict(out_bf16=True)),
-                                ((N, co, D, 2 * Hh, 2 * W), H.RES_POOL, {})]:
-        r = rnd(*res_shape, seed=16)
-        if kw.get("out_f16"):
-            r = r.half()
-        if kw.get("out_bf16"):
-            r = r.bfloat16()
-        rd = hc.to_ndhwc(r).cuda()
-        for precision in (3, 6):
-            if kw.get("out_f16") and precision == 6:
-                continue
-            o1, s1, _ = hc.conv3d([x], w, b, (D, Hh, W), res=rd, res_mode=mode, precision=precision, **kw)
-            assert hc.LAST_PLAN["fused"]
-            o2, s2, _ = hc.conv3d([x], w, b, (D, Hh, W), res=rd, res_mode=mode, precision=precision,
-                                  hint=H.HINT_SPLITK_TWO_LAUNCH, **kw)
-            assert torch.isfinite(o1.float()).all() and torch.equal(o1, o2)
-            assert torch.allclose(s1.sum(dim=2), s2.sum(dim=2), rtol=1e-9, atol=1e-6)
 
 
 @pytest.mark.parametrize("precision", [1, 2, 5])

@@ -55,14 +55,13 @@ def test_library_exports_every_declared_symbol():
     # 64x32x32 level: 128-voxel tiles (2x8x8)
     assert lib.ddpm3d_conv_stats_rows(1, 64, 32, 32, 128, 128, 3, 3) == 32 * 4 * 4
     assert lib.ddpm3d_conv_workspace_bytes(1, 64, 64, 64, 128, 128, 3, 3) == 0
-    # 64x4x4 level: 8 voxel tiles -> split over Cin, combined INSIDE the launch by the last workgroup to arrive at
-    # a tile (r04): one statistics row per tile, as an unsplit launch writes them (the reduce launch of r01-r03
-    # wrote one row per 4 voxels here: 256)
-    assert lib.ddpm3d_conv_stats_rows(1, 64, 4, 4, 512, 512, 3, 3) == 8
-    assert lib.ddpm3d_conv_stats_rows(8, 64, 4, 4, 512, 512, 3, 3) == 8
-    # workspace = arrival counters (one word per (tile, 128-cout block), 256-byte multiple) + S whole output tensors
+    # 64x4x4 level: 8 voxel tiles -> split over Cin; the reduce kernel's rows shrink from 16 to 4
+    # voxels on this level so that it still launches >= 1024 workgroups (256 rows x 2 quad blocks)
+    assert lib.ddpm3d_conv_stats_rows(1, 64, 4, 4, 512, 512, 3, 3) == 256
+    # eight samples of the same level: 8 x 64 rows x 2 quad blocks of 16 voxels already fill it
+    assert lib.ddpm3d_conv_stats_rows(8, 64, 4, 4, 512, 512, 3, 3) == 64
     ws = lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 512, 512, 3, 3)
-    assert ws > 0 and ws % (1024 * 512 * 4) == 256
+    assert ws > 0 and ws % (1024 * 512 * 4) == 0
 
 
 def test_split_rule_and_prepass_argument_checks_without_a_gpu():
@@ -77,10 +76,10 @@ def test_split_rule_and_prepass_argument_checks_without_a_gpu():
         out_bytes = D * H * W * co * 4
         for prec in ((3, 6, 0) if k == 3 else (1, 5, 0)):      # the rule is per arithmetic mode since ABI 12
             ws = lib.ddpm3d_conv_workspace_bytes(1, D, H, W, ci, co, k, prec)
-            assert ws % out_bytes in (0, 256, 512)         # + the in-launch combine's arrival counters
+            assert ws % out_bytes == 0
             S = ws // out_bytes
             assert S <= (16 if k == 3 else ci // 16), (D, H, W, ci, co, k, prec, S)
-    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 1024, 384, 3, 3) == 256 + 16 * 64 * 4 * 4 * 384 * 4
+    assert lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 1024, 384, 3, 3) == 16 * 64 * 4 * 4 * 384 * 4
     assert lib.ddpm3d_conv_workspace_bytes(1, 64, 4, 4, 1024, 384, 3, 7) == 0      # unknown precision
     lib.ddpm3d_pool_act.restype = ctypes.c_int
     vp = ctypes.c_void_p
@@ -279,3 +278,40 @@ def test_integration_doc_binds_the_current_abi():
     readme = open(os.path.join(ROOT, "README.md")).read()
     r = re.search(r"ABI version (\d+)", readme)
     assert r and int(r.group(1)) == _hip.ABI_VERSION
+
+
+def test_unet_desc_struct_layouts_match_the_header():
+    """The ctypes mirrors of ddpm3d_conv_weights / ddpm3d_layer / ddpm3d_unet_desc have the field order, sizes and
+    offsets a C compiler gives the header's structs (checked against a tiny C program compiled here with gcc)."""
+    import subprocess
+    import tempfile
+    from conftest import ROOT
+    src = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "ddpm3d.h"
+int main(void) {
+    printf("%zu %zu %zu %zu %zu\n", sizeof(ddpm3d_conv_weights), offsetof(ddpm3d_conv_weights, bias), offsetof(ddpm3d_conv_weights, Cout),
+           offsetof(ddpm3d_conv_weights, precision_wz), (size_t)0);
+    printf("%zu %zu %zu %zu %zu\n", sizeof(ddpm3d_layer), offsetof(ddpm3d_layer, norm1_gamma), offsetof(ddpm3d_layer, conv1),
+           offsetof(ddpm3d_layer, conv2), offsetof(ddpm3d_layer, skip));
+    printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ddpm3d_unet_desc), offsetof(ddpm3d_unet_desc, layers),
+           offsetof(ddpm3d_unet_desc, input_block_layers), offsetof(ddpm3d_unet_desc, output_block_layers),
+           offsetof(ddpm3d_unet_desc, first), offsetof(ddpm3d_unet_desc, out), offsetof(ddpm3d_unet_desc, arithmetic));
+    return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "layout.c")
+        with open(c, "w") as f:
+            f.write(src)
+        exe = os.path.join(td, "layout")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
+    W, L, U = _hip.ConvWeights, _hip.Layer, _hip.UnetDesc
+    assert [int(v) for v in out[0].split()][:4] == [ctypes.sizeof(W), W.bias.offset, W.Cout.offset, W.precision_wz.offset]
+    assert [int(v) for v in out[1].split()] == [ctypes.sizeof(L), L.norm1_gamma.offset, L.conv1.offset, L.conv2.offset,
+                                                L.skip.offset]
+    assert [int(v) for v in out[2].split()] == [ctypes.sizeof(U), U.layers.offset, U.input_block_layers.offset,
+                                                U.output_block_layers.offset, U.first.offset, U.out.offset,
+                                                U.arithmetic.offset]

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--libs", default=None, help="space-separated library paths relative to the repo root ('-' = in-tree)")
     ap.add_argument("--trees", default=None, help="space-separated tree directories relative to the repo root")
     ap.add_argument("--flags", default=None, help="'|'-separated sets of extra forward_time.py flags, one variant each "
-                                                  "(e.g. '|--two-launch|--graph'; an empty set = the defaults)")
+                                                  "(e.g. '|--graph'; an empty set = the defaults)")
     ap.add_argument("--rounds", type=int, default=int(os.environ.get("ROUNDS", "2")))
     ap.add_argument("rest", nargs=argparse.REMAINDER)
     a = ap.parse_args()
@@ -58,7 +58,7 @@ def main():
                     cwd = os.path.join(ROOT, v)
                 fe.write("==== round %d %s\n" % (r, v))
                 fe.flush()
-                p = subprocess.run([sys.executable, os.path.join(cwd, "tools", "forward_time.py"), "--tag", v or "default"]
+                p = subprocess.run([sys.executable, os.path.join(cwd, "tools", "forward_time.py"), "--tag", (v or "default").replace("-", "_")]
                                    + extra + rest,
                                    cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=fe, text=True)
                 line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -50,7 +50,7 @@ def main():
     rows = lib.ddpm3d_conv_stats_rows(N, D, Hh, W, a.cin, a.cout, a.k, a.precision)
     stats = torch.empty(N, a.cout, rows, 2, dtype=torch.float64, device=dev)
     need = lib.ddpm3d_conv_workspace_bytes(N, D, Hh, W, a.cin, a.cout, a.k, a.precision)
-    ws = torch.zeros(max(need, 16), dtype=torch.uint8, device=dev)    # (zero: arrival counters, ddpm3d.h)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
     d = H.ConvDesc()
     d.N, d.D, d.H, d.W, d.Cin, d.Cout, d.ksize, d.in_mode = N, D, Hh, W, a.cin, a.cout, a.k, H.IN_SAME
     d.src0, d.C0 = H.ptr(x), a.cin

@@ -32,11 +32,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tag", default="")
     ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph of the forward (engine step_graph)")
-    ap.add_argument("--two-launch", action="store_true",
-                    help="combine split convs in a reduce launch of their own (DDPM3D_HINT_SPLITK_TWO_LAUNCH)")
     a = ap.parse_args()
-    if a.two_launch:
-        os.environ["DDPM3D_SPLITK_TWO_LAUNCH"] = "1"      # read when the engine is built
     dev = torch.device("cuda:0")
     model, _, _ = bench.build_model(bench.PUBLISHED, "250", dev)
     model.conv_precision = a.precision
@@ -70,7 +66,7 @@ def main():
                 f[0] += 1
                 f[1] += a0.elapsed_time(a1)
             plan.timing = None
-    print(json.dumps({"tag": a.tag, "lib": os.environ.get("DDPM3D_LIB", "in-tree"), "precision": a.precision, "graph": a.graph, "two_launch": a.two_launch,
+    print(json.dumps({"tag": a.tag, "lib": os.environ.get("DDPM3D_LIB", "in-tree"), "precision": a.precision, "graph": a.graph,
                       "ms_per_forward": round(ms, 4),
                       "families_ms": {k: round(v[1] / 3, 4) for k, v in sorted(fam.items())}}))
 

@@ -42,7 +42,6 @@ SPLITS = [1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24, 32]
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ksize", type=int, default=3)
-    ap.add_argument("--two-launch", action="store_true", help="combine the slabs in a reduce launch of its own (the form until r03)")
     ap.add_argument("--precision", type=int, default=None, help="C ABI precision code (default 3 for ksize 3, 1 for ksize 1)")
     a = ap.parse_args()
     ks = a.ksize
@@ -50,9 +49,8 @@ def main():
     lib = H.load()
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(0)
-    print("# %s conv (precision code %d), split over Cin combined %s, ms per layer at forced split factors (median of 5 x 10 launches);"
-          % ("f16x3 Winograd-D" if ks == 3 and prec == 3 else "%dx%dx%d" % (ks, ks, ks), prec,
-             "in a reduce launch of its own" if a.two_launch else "inside the conv launch (last arriver)"))
+    print("# %s conv (precision code %d) + split-K reduce, ms per layer at forced split factors (median of 5 x 10 launches);"
+          % ("f16x3 Winograd-D" if ks == 3 and prec == 3 else "%dx%dx%d" % (ks, ks, ks), prec))
     print("# 'auto' = the library's choice with the same descriptor%s" % (" (with GroupNorm partial sums)" if ks == 3 else ""))
     print("%-22s %5s | %s" % ("Cin->Cout @ DxHxW", "auto", "  ".join("S=%-5d" % s for s in SPLITS)))
     for ci, co, D, Hh, W in (SHAPES if ks == 3 else SHAPES_1X1):
@@ -64,8 +62,7 @@ def main():
         wp = torch.empty(lib.ddpm3d_packed_weight_bytes(co, ci, ks, prec), dtype=torch.uint8, device=dev)
         H.check(lib.ddpm3d_pack_conv_weight(H.ptr(w), co, ci, ks, prec, H.ptr(wp), H.stream()))
         out = torch.empty(1, D, Hh, W, co, device=dev)
-        # (zero: the front of the workspace holds the in-launch combine's arrival counters; + 1 MB for them)
-        ws = torch.zeros(max(SPLITS) * out.numel() * 4 + (1 << 20), dtype=torch.uint8, device=dev)
+        ws = torch.empty(max(SPLITS) * out.numel() * 4, dtype=torch.uint8, device=dev)
         stats = torch.empty(co * (D * Hh * W // 4 + 1) * 2, dtype=torch.float64, device=dev) if ks == 3 else None
         bound = torch.full((1, 1), 8.0, device=dev)
         d = H.ConvDesc()
@@ -79,7 +76,7 @@ def main():
         d.workspace, d.workspace_bytes = H.ptr(ws), ws.numel()
 
         def run(hint):
-            d.kernel_hint = hint | (H.HINT_SPLITK_TWO_LAUNCH if a.two_launch else 0)
+            d.kernel_hint = hint
             d.stats, d.stats_rows = 0, 0
             if stats is not None:       # the network's 3x3x3 convs all emit GroupNorm partial sums
                 d.stats, d.stats_rows = H.ptr(stats), H.conv_plan(d)[0]
@@ -101,7 +98,8 @@ def main():
         cells = []
         for s in SPLITS:
             cells.append("%7.4f" % run(s << H.HINT_SPLITK_SHIFT) if s <= nch and (s == 1 or (nch + s - 1) // s >= 1) else "      -")
-        d.kernel_hint = H.HINT_SPLITK_TWO_LAUNCH if a.two_launch else 0
+        d.kernel_hint = 0
+        d.stats, d.stats_rows = 0, 0
         s_auto = H.conv_plan(d)[2]
         print("%-22s %5.4f (S=%d) | %s" % ("%d->%d @ %dx%dx%d" % (ci, co, D, Hh, W), auto, s_auto, "  ".join(cells)))
 
