@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--probe-ms", type=float, default=50.0,
                     help="length of the MFMA calibration loop (roofline.device_sustained_tflops; 0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for cpu_baseline")
+    ap.add_argument("--golden", type=int, choices=[0, 1], default=1,
+                    help="one more volume against the reference's own 250-step sample (tests/golden/sampler250_64.npz)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--precision", choices=["f32", "f16x3", "f16", "bf16"],
@@ -546,6 +548,29 @@ def main():
                 "rel_err": rel_err(first_sample, sample32), "psnr_db": round(psnr_db(first_sample, sample32), 2)}
             log("[bench] parity vs exact f32: rel %.2e, PSNR %.1f dB"
                 % (parity["vs_exact_f32"]["rel_err"], parity["vs_exact_f32"]["psnr_db"]))
+
+    # "PSNR vs ref" of the metric, on the headline workload itself: ONE more volume of the same configuration with
+    # the weights, conditioning volume and injected noise of tests/golden/sampler250_64.npz -- the REFERENCE's own
+    # 250-step run of BASELINE config 2 (generated in the build container, tests/golden/make_golden.py) -- against
+    # that file's final sample.  A fixture, not the oracle: nothing under /root/reference is read here.
+    gold = os.path.join(ROOT, "tests", "golden", "sampler250_64.npz")
+    if (rank == 0 and world == 1 and args.arch == "published" and S == 64 and T == 250 and args.sampler == "ddpm"
+            and not overrides and os.path.exists(gold) and args.golden):
+        from guided_diffusion import synth as _synth
+        g = np.load(gold)
+        shp = (1, 1, S, S, S)
+        draws = [torch.from_numpy(a).to(device) for a in _synth.synth_noise(shp, T + 1, seed=10)]
+        lrg = torch.from_numpy(_synth.synth_low_res(shp, seed=1234)).to(device)
+        got = diff.p_sample_loop(model, shp, draws[0], model_kwargs={"low_res": lrg}, step_noise=draws[1:]).cpu()
+        ref = torch.from_numpy(g["sample"])
+        parity["vs_reference"] = {
+            "what": "this configuration (1x64^3, %d DDPM steps, published architecture, %s arithmetic) on the weights, "
+                    "conditioning volume and injected noise of tests/golden/sampler250_64.npz, against that file: the "
+                    "reference's own final sample" % (T, args.precision),
+            "rel_err": rel_err(got, ref), "psnr_db": round(psnr_db(got, ref), 2)}
+        del draws
+        log("[bench] parity vs the reference's own 250-step run: rel %.2e, PSNR %.1f dB"
+            % (parity["vs_reference"]["rel_err"], parity["vs_reference"]["psnr_db"]))
 
     if rank == 0:
         vols = args.steps * B * world

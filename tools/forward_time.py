@@ -32,11 +32,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tag", default="")
     ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph of the forward (engine step_graph)")
+    ap.add_argument("--native", action="store_true", help="run on the C-level plan (ddpm3d_unet_forward)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     model, _, _ = bench.build_model(bench.PUBLISHED, "250", dev)
     model.conv_precision = a.precision
     model.step_graph = a.graph
+    model.native_plan = a.native
     S, B = a.size, a.batch
     shape = (B, 1, S, S, S)
     x = torch.from_numpy(synth.synth_noise(shape, 1, seed=3)[0]).to(dev)
@@ -55,6 +57,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
+        eng.native_plan = False                    # the per-family table comes from the instrumented Python plan
         plan = eng.plan(B, S, S, S)
         fam = {}
         for _ in range(3):
@@ -66,7 +69,7 @@ def main():
                 f[0] += 1
                 f[1] += a0.elapsed_time(a1)
             plan.timing = None
-    print(json.dumps({"tag": a.tag, "lib": os.environ.get("DDPM3D_LIB", "in-tree"), "precision": a.precision, "graph": a.graph,
+    print(json.dumps({"tag": a.tag, "lib": os.environ.get("DDPM3D_LIB", "in-tree"), "precision": a.precision, "graph": a.graph, "native": a.native,
                       "ms_per_forward": round(ms, 4),
                       "families_ms": {k: round(v[1] / 3, 4) for k, v in sorted(fam.items())}}))
 

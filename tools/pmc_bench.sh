@@ -13,7 +13,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/$c" -- \
-        python3 "$R/bench.py" --steps 1 --warmup 0 --ddpm-steps 2 --cpu-steps 0 --f32-steps 0 --probe-ms 0 "$@" > "$OUT/$c.log" 2>&1 || exit 1
+        python3 "$R/bench.py" --steps 1 --warmup 0 --ddpm-steps 2 --cpu-steps 0 --f32-steps 0 --probe-ms 0 --golden 0 "$@" > "$OUT/$c.log" 2>&1 || exit 1
 done
 python3 - "$OUT" <<'EOF'
 import collections, csv, glob, json, re, sys

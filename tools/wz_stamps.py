@@ -93,17 +93,12 @@ def main():
     print("# conv3d_wz_kernel stamps, %d->%d @ %dx%dx%d, precision %d%s: %.3f ms (instrumented; conv + reduce if split), "
           "%d workgroups, split %d, %d chunks each"
           % (a.cin, a.cout, D, Hh, W, a.precision, ", residual" if a.res else "", ms, nwg, S, nch))
-    span = s[:, :, 43].max() - s[:, :, 0].min()
-    rt = s[:, :, 46]
-    print("kernel span %d cycles; shader clock ~%.3f GHz (span / event time)" % (span, span / (ms * 1e6)))
-
     def stat(name, v):
         v = np.asarray(v).ravel()
         print("%-44s median %8.0f  mean %8.0f  p10 %8.0f  p90 %8.0f" % (name, np.median(v), v.mean(),
                                                                         np.percentile(v, 10), np.percentile(v, 90)))
     stat("wave lifetime", life)
-    stat("wave start after the first wave's start", s[:, :, 0] - s[:, :, 0].min())
-    stat("wave end after the first wave's start", s[:, :, 43] - s[:, :, 0].min())
+    # (s_memtime is per XCD: differences are meaningful within one wave / one XCD only, never across the launch)
     stat("prologue (entry -> first stage issued)", s[:, :, 1] - s[:, :, 0])
     c = np.arange(nch)
     b1 = s[:, :, 3 + 5 * c] - s[:, :, 2 + 5 * c]
