@@ -121,7 +121,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     WZ_STAMP(1);
 
     constexpr int L = X3 ? 1 : 0;   // index of the lo halves (unused slot 0 alias in the f16 form)
-    constexpr int R = X3 ? 3 : 8;
+    // f16x3: ring of 4 taps (r04).  The r01-r03 ring of 3 "because the registers are full" overlooked that the ring empties
+    // while the next chunk's raw staging registers fill (taps 33-35): with the staging loads pinned at tap NT - 3 a deeper
+    // ring costs no register at the point of highest pressure (240 VGPRs at depth 4 on 8x4x4 tiles, no spill; 248 at 5;
+    // the 4x4x8 form spills from 5).  Same box (profiles/r04_lib_ab_weight_ring_f16x3.txt): depth 3 / 4 / 5 / 6 =
+    // 12.95 / 12.75 / 12.79 / 12.88 ms per forward; the 4x4x8 family, whose weights come from HBM, 0.842 -> 0.788.
+#ifndef DDPM3D_WZ_RING_X3
+#define DDPM3D_WZ_RING_X3 4
+#endif
+#ifndef DDPM3D_WZ_RING_X1
+#define DDPM3D_WZ_RING_X1 8
+#endif
+    constexpr int R = X3 ? DDPM3D_WZ_RING_X3 : DDPM3D_WZ_RING_X1;
+    // the next chunk's raw loads are issued behind the chunk's LAST weight loads (vmcnt retires in order): at tap NT - R
+    // in the one-MFMA forms; a deeper f16x3 ring stops loading earlier, and its staging loads still go out at tap NT - 3,
+    // when ring slots have started to free up (the raw registers take their place)
+    constexpr int STAGE_TAP = X3 ? NT - 3 : NT - 8;
     for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         const bool more = chunk + 1 < chunk_end;
         const unsigned char* bufc = lds;
@@ -152,26 +167,27 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
             if (X3) bq[s][L] = buffer_load16(wrsrc, wlane, woff + wpart);
             bump();
         }
-        h8 af[2][2][X3 ? 2 : 1];   // [slot][row tile][hi|lo]: A operands, read one tap ahead
+#ifndef DDPM3D_WZ_A_AHEAD
+#define DDPM3D_WZ_A_AHEAD 1     // taps the A operands are read ahead of their use (measurement: 2)
+#endif
+        constexpr int AH = DDPM3D_WZ_A_AHEAD, AS = AH + 1;
+        h8 af[AS][2][X3 ? 2 : 1];   // [slot][row tile][hi|lo]: A operands, read AH tap(s) ahead
+        auto aread = [&](const int t1) {
+            const int off1 = ((t1 / 9) * RZ + ((t1 / 3) % 3) * RY + (t1 % 3) * VS) * 16;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            af[0][t][0] = *reinterpret_cast<const h8*>(bufc + arow[t]);
-            if (X3) af[0][t][L] = *reinterpret_cast<const h8*>(bufc + arow[t] + 32);
-        }
+            for (int t = 0; t < 2; ++t) {
+                af[t1 % AS][t][0] = *reinterpret_cast<const h8*>(bufc + arow[t] + off1);
+                if (X3) af[t1 % AS][t][L] = *reinterpret_cast<const h8*>(bufc + arow[t] + off1 + 32);
+            }
+        };
+#pragma unroll
+        for (int t1 = 0; t1 < AH; ++t1) aread(t1);
 #pragma unroll
         for (int tap = 0; tap < NT; ++tap) {
             // pin the tap boundary: the scheduler otherwise moves the LDS reads (and, in long
             // straight-line runs, the weight loads) down to their first use
             __builtin_amdgcn_sched_barrier(0);
-            if (tap + 1 < NT) {
-                const int t1 = tap + 1;
-                const int off1 = ((t1 / 9) * RZ + ((t1 / 3) % 3) * RY + (t1 % 3) * VS) * 16;
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    af[t1 & 1][t][0] = *reinterpret_cast<const h8*>(bufc + arow[t] + off1);
-                    if (X3) af[t1 & 1][t][L] = *reinterpret_cast<const h8*>(bufc + arow[t] + off1 + 32);
-                }
-            }
+            if (tap + AH < NT) aread(tap + AH);
             if (tap + R - 1 < NT) {
                 bq[(tap + R - 1) % R][0] = buffer_load16(wrsrc, wlane, woff);
                 if (X3) bq[(tap + R - 1) % R][L] = buffer_load16(wrsrc, wlane, woff + wpart);
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
             }
             if constexpr (!IL) __builtin_amdgcn_sched_barrier(0);   // prefetches issue BEFORE this tap's MFMAs
             // next chunk's raw loads: after the chunk's last weight loads (vmcnt retires in order)
-            if (tap == NT - R && more) stage_issue(p, sl, raw, n, z0, chunk + 1);
+            if (tap == STAGE_TAP && more) stage_issue(p, sl, raw, n, z0, chunk + 1);
             const int j = tap / 9;
             const h8 bhi = __builtin_bit_cast(h8, bq[tap % R][0]);
             // per accumulator the order stays lo*hi, hi*lo, hi*hi; the two row tiles alternate
@@ -187,14 +203,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
                 const h8 blo = __builtin_bit_cast(h8, bq[tap % R][L]);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    acc[j][t] = mfma16<false>(af[tap & 1][t][L], bhi, acc[j][t]);
+                    acc[j][t] = mfma16<false>(af[tap % AS][t][L], bhi, acc[j][t]);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    acc[j][t] = mfma16<false>(af[tap & 1][t][0], blo, acc[j][t]);
+                    acc[j][t] = mfma16<false>(af[tap % AS][t][0], blo, acc[j][t]);
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                acc[j][t] = mfma16<MODE == WZ_BF16>(af[tap & 1][t][0], bhi, acc[j][t]);
+                acc[j][t] = mfma16<MODE == WZ_BF16>(af[tap % AS][t][0], bhi, acc[j][t]);
             if constexpr (IL == 1 || IL == 3) {
 #pragma unroll
                 for (int i = 0; i < (X3 ? 4 : 2); ++i) {
