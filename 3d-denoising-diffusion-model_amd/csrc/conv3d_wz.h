@@ -148,12 +148,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
         __syncthreads();
         WZ_STAMP(5 + (chunk - chunk_begin) * 5);
 
-        // ---- 36 taps (j, dy, dx); weight ring of R taps, prefetch distance R - 1: 2 in the f16x3 form
-        // (a deeper one measured no different, and the registers are full), 7 in the one-MFMA-per-
-        // product forms, whose taps are three times shorter against the same L2 latency (r02, same
-        // box, bf16 DDIM-50: R = 3 / 4 / 6 / 8 / 9 -> 2.19 / 2.34 / 2.42 / 2.48 / 2.39 volumes/s; the
-        // A operands one tap ahead as below: two ahead -1.5 %, three -16 %).  The stream's byte
-        // offset is one running scalar
+        // ---- 36 taps (j, dy, dx); weight ring of R taps, prefetch distance R - 1: 3 in the f16x3 form
+        // (r04, see R above; 2 until r03), 7 in the one-MFMA-per-product forms, whose taps are three
+        // times shorter against the same L2 latency (r02, same box, bf16 DDIM-50: R = 3 / 4 / 6 / 8 / 9
+        // -> 2.19 / 2.34 / 2.42 / 2.48 / 2.39 volumes/s; r04: 10 / 12 with the staging loads pinned at
+        // tap 28: no better; the A operands one tap ahead as below: two ahead -1.5 %, three -16 %).
+        // The stream's byte offset is one running scalar
         if constexpr (IL == 3 || IL == 4 || IL == 6) __builtin_amdgcn_s_setprio(1);
         unsigned woff = (unsigned)chunk * wchunk_stride;
         auto bump = [&]() {

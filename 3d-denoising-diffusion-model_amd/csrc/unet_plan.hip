@@ -286,6 +286,13 @@ struct Planner {
     }
 
     bool layer(const ddpm3d_layer& e, const Act* s0, const Act* s1, Act* out) {
+        // a description with a hole in it is refused here, not discovered by a kernel
+        const bool n1 = e.norm1_gamma && e.norm1_beta, n2 = e.norm2_gamma && e.norm2_beta;
+        const bool c1 = e.conv1.w_packed && e.conv1.bias, c2 = e.conv2.w_packed && e.conv2.bias;
+        if (e.kind == DDPM3D_LAYER_RES && !(n1 && n2 && c1 && c2 && (!e.skip.w_packed || e.skip.bias)))
+            return fail("ResBlock description without its norms / convs");
+        if (e.kind == DDPM3D_LAYER_ATTN && !(n1 && c1 && c2)) return fail("AttentionBlock description without norm / qkv / proj_out");
+        if ((e.kind == DDPM3D_LAYER_UPCONV || e.kind == DDPM3D_LAYER_DOWNCONV) && !c1) return fail("resampling conv without weights");
         if (e.kind == DDPM3D_LAYER_RES) return resblock(e, s0, s1, out);
         if (e.kind == DDPM3D_LAYER_ATTN) return attention(e, s0, out);
         if (e.kind == DDPM3D_LAYER_UPCONV || e.kind == DDPM3D_LAYER_DOWNCONV) {

@@ -42,7 +42,10 @@ def create_argparser():
                     timestep_respacing="", base_samples="", model_path="",
                     # launch-side extras (not in the reference): collective backend ("" = RCCL on
                     # GPUs) and all ranks on cuda:0, to rehearse the multi-rank flow on a one-GPU box
-                    dist_backend="", share_gpu=False)
+                    dist_backend="", share_gpu=False,
+                    # one captured hipGraph per UNet forward / the library's own launch plan (both bit-identical
+                    # to the default launch-by-launch replay of the Python plan)
+                    step_graph=False, native_plan=False)
     defaults.update(sr_model_and_diffusion_defaults())
     parser = argparse.ArgumentParser()
     add_dict_to_argparser(parser, defaults)
@@ -67,6 +70,7 @@ def main(argv=None):
     model.to(dev)
     if args.use_fp16:
         model.convert_to_fp16()
+    model.step_graph, model.native_plan = args.step_graph, args.native_plan
     model.eval()
 
     logger.log("loading data...")
