@@ -173,3 +173,28 @@ def test_c_abi_from_plain_cpp(tmp_path):
     print(r.stdout)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     assert "C ABI OK" in r.stdout
+
+
+def test_whole_network_from_plain_cpp(tmp_path):
+    """SURVEY 8b's `unet_forward(handle, ...)` granularity from a host that is neither Python nor torch:
+    tests/c_abi/unet_from_c.cpp describes a small FiLM-conditioned SuperRes UNet (encoder, middle and decoder
+    ResBlocks, the decoder's virtual concat with 1x1 skip convs) with ddpm3d_unet_desc, has the library compile
+    the launch plan into one hipMalloc'ed arena (ddpm3d_unet_plan_create), runs ddpm3d_unet_forward twice
+    (bit-identical replays) and checks the output against its own fp64 evaluation of the network on the host;
+    an undersized arena is refused."""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    csrc = os.path.join(PKG, "csrc")
+    exe = str(tmp_path / "unet_from_c")
+    cmd = [hipcc, "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c_abi", "unet_from_c.cpp"),
+           "-L", csrc, "-lddpm3d", "-Wl,-rpath," + csrc, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert "PASS" in r.stdout and "bit-identical" in r.stdout
