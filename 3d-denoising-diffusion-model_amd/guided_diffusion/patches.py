@@ -96,8 +96,8 @@ def stitch_patches(patches_hwz, grid, shape_dhw, resolution):
 
 def load_volume(path):
     """Input volume as (D,H,W) float32.  .npz ('arr_0' or the first array) and .npy
-    always; .tif/.tiff when tifffile is importable (scripts/test.py reads tif only,
-    README.md:67 tells users to edit the loader for other formats)."""
+    besides the reference's .tif/.tiff (tiff_io: tifffile when importable, else its own reader; scripts/test.py
+    reads tif only, README.md:67 tells users to edit the loader for other formats)."""
     low = path.lower()
     if low.endswith(".npz"):
         with np.load(path, allow_pickle=False) as z:
@@ -106,11 +106,8 @@ def load_volume(path):
     elif low.endswith(".npy"):
         vol = np.load(path, allow_pickle=False)
     elif low.endswith((".tif", ".tiff")):
-        try:
-            import tifffile
-        except ImportError as e:
-            raise RuntimeError("reading %s needs the tifffile package" % path) from e
-        vol = tifffile.imread(path)
+        from . import tiff_io
+        vol = tiff_io.imread(path)
     else:
         raise ValueError("unsupported input file type: %s" % path)
     vol = np.asarray(vol)

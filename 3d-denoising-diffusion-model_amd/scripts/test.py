@@ -128,8 +128,10 @@ def main(argv=None):
         logger.log(f"saving to {out_path}")
         np.savez(out_path, result)                                           # key 'arr_0', (H,W,Z) like the reference
         if args.base_samples.lower().endswith((".tif", ".tiff")):
-            import tifffile
-            tifffile.imwrite(out_path.replace(".npz", ".tif"), result.transpose(2, 0, 1).astype(np.float32))
+            from guided_diffusion import tiff_io
+            tiff_path = out_path.replace(".npz", ".tif")
+            tiff_io.imwrite(tiff_path, result.transpose(2, 0, 1).astype(np.float32))   # (H,W,Z) -> (Z,H,W), no scaling
+            logger.log(f"Saved denoised TIFF: {tiff_path}")
     dist_util.barrier()
     logger.log("Full image denoising complete")
     return out_path
