@@ -89,6 +89,21 @@ __global__ __launch_bounds__(256, DDPM3D_PW_WGS) void conv3d_pw_kernel(const Con
 
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Measurement build only (-DDDPM3D_PW_STAMPS, tools/pw_stamps.py; never in the shipped library): s_memtime at
+    // entry / first loads issued / first block done / loop done / epilogue done, dumped to the workspace
+#ifdef DDPM3D_PW_STAMPS
+    unsigned long long pw_st[5];
+#define PW_STAMP(i) pw_st[i] = __builtin_amdgcn_s_memtime()
+#define PW_DUMP() do { if (p.partial != nullptr && p.ksplit == 1 && lane == 0) { \
+        const size_t wgl = blockIdx.x + (size_t)gridDim.x * blockIdx.y; \
+        unsigned long long* dump = reinterpret_cast<unsigned long long*>(p.partial) + (wgl * 4 + wave) * 8; \
+        for (int i = 0; i < 5; ++i) dump[i] = pw_st[i]; \
+        dump[5] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define PW_STAMP(i) do { } while (0)
+#define PW_DUMP() do { } while (0)
+#endif
+    PW_STAMP(0);
     const WgId wg = wg_id(p);
     int tile = wg.tile;
     const int tx_i = tile % p.tilesX; tile /= p.tilesX;
@@ -211,15 +226,47 @@ __global__ __launch_bounds__(256, DDPM3D_PW_WGS) void conv3d_pw_kernel(const Con
     if (bb < be) {
         pw_static_for<0, D>([&](auto u) { issue(u, bb + decltype(u)::value); });
         if constexpr (PREC == 1 || PREC == 2) asc = act_scale_finish(bound_raw, 1.0f);
-        for (int b = bb; b < be; b += D)
+        PW_STAMP(1);
+        for (int b = bb; b < be; b += D) {
             pw_static_for<0, D>([&](auto u) { block(u, b + decltype(u)::value); });
+#ifdef DDPM3D_PW_STAMPS
+            if (b == bb) PW_STAMP(2);
+#endif
+        }
     }
+    PW_STAMP(3);
 
     const int tile_in_n = (tz_i * p.tilesY + ty_i) * p.tilesX + tx_i;
+    // The four accumulators are four cout blocks, each with its own output scale and bias: all eight values are
+    // requested HERE, in one round trip.  Left to the four epilogue calls they are four dependent round trips in a
+    // row (no load moves above the previous call's stores), which was most of the epilogue's 15.7 k cycles -- itself
+    // half the life of a wave on the short layers (profiles/r04_pw_stamps_*.txt).  (Requested at kernel START they
+    // stay live through the K loop, which then spills: r03.)
+    float ws[4], bs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cout = wg.cy * 128 + j * 32 + (lane & 31);
+        const bool cv = cout < p.Cout;
+        ws[j] = cv ? p.wscale[cout] : 1.0f;
+        bs[j] = (cv && p.ksplit == 1) ? p.bias[(size_t)n * p.bias_stride_n + cout] : 0.0f;
+    }
+    if constexpr (WIDE) {
+        f32x16 accs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accs[j] = acc[j][0];
+        if (conv_epilogue_lean<PREC, 4, 1, 4, TXL, TYL, false, false>(p, accs, n, z0, y0, x0, tile_in_n, wave,
+                                                                     wg.cy * 128 + (lane & 31), g, wg.split, asc.inv, ws, bs)) {
+            PW_STAMP(4);
+            PW_DUMP();
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
         conv_epilogue<PREC, 4, 1, TXL, TYL, WIDE>(p, acc[j], n, z0, y0, x0, tile_in_n, wave,
-                                                  wg.cy * 128 + j * 32 + (lane & 31), g, wg.split, asc.inv);
+                                                  wg.cy * 128 + j * 32 + (lane & 31), g, wg.split, asc.inv, true, ws[j], bs[j]);
+    PW_STAMP(4);
+    PW_DUMP();
 }
 
 template <int PREC, int S16, int TXL, int TYL>

@@ -67,6 +67,132 @@ __device__ __forceinline__ constexpr int epi_tz(int m) {
     return ZPAIRS ? 2 * ((((u & 1) << 5) + r) >> (TXL + TYL)) + (u >> 1) : m >> (TXL + TYL);
 }
 
+// ---- The lean 16-byte epilogue (r04).  conv_epilogue below decides everything at run time and computes, before its
+// first branch, what every one of its paths needs (sample sizes and residual bases of the up / down forms, both store
+// forms' lane offsets, 64-bit products): ~500 scalar instructions that a wave issues one by one, with half of its
+// ~100 wave-uniform values parked in VGPR lanes (v_readlane / v_writelane).  Phase stamps put that epilogue at
+// 15.7 k cycles for the 16 stores of a 1x1 workgroup -- half its life on the short layers -- and at 9.5-14 k in the
+// Winograd kernels (profiles/r04_pw_stamps_*.txt, r04_wz_stamps_*.txt).  This function is the same arithmetic in the
+// same order (bit-identical results) for the case nearly every launch of the network is: tile inside the volume,
+// NDHWC output (or a split launch's slab), no residual or a same-shape one, Cout % 4 == 0.  It returns false without
+// side effects when the launch is anything else; the caller then runs conv_epilogue.
+//   acc   NJ cout blocks (couts cout0 + 32 j) x MT row tiles; ws / bs: the blocks' output scale and bias
+//   every residual load of the wave is issued before its first store (in-place residuals: out == res is allowed)
+template <int PREC, int WM, int MT, int NJ, int TXL, int TYL, bool ZPAIRS, bool KSPLIT>
+__device__ __forceinline__ bool conv_epilogue_lean(const ConvK& p, const f32x16 (&acc)[NJ * MT], int n, int z0, int y0, int x0,
+                                                   int tile_in_n, int wm, int cout0, int half, int ksplit_idx, float inv_act,
+                                                   const float (&ws)[NJ], const float (&bs)[NJ]) {
+    constexpr int TX = 1 << TXL, TY = 1 << TYL, TZ = WM * MT * 32 / (TX * TY);
+    const bool split = KSPLIT || p.ksplit > 1;
+    const int rm = split ? DDPM3D_RES_NONE : p.res_mode;
+    const size_t samp = (size_t)p.D * p.H * p.W * p.Cout;              // elements per sample
+    const bool ok = z0 + TZ <= p.D && y0 + TY <= p.H && x0 + TX <= p.W && p.out_layout == DDPM3D_OUT_NDHWC &&
+                    (rm == DDPM3D_RES_NONE || rm == DDPM3D_RES_SAME) && (p.Cout & 3) == 0 && samp * 4 < 0xFFFFFFF0ull;
+    if (!ok) return false;
+    const bool resid = rm == DDPM3D_RES_SAME;
+    const bool o16 = !split && (p.io & DDPM3D_IO_OUT_BF16), r16 = (p.io & DDPM3D_IO_RES_BF16) != 0;
+    const bool f16 = (p.io & DDPM3D_IO_HALF_IS_F16) != 0;
+    const unsigned eso = o16 ? 2u : 4u, esr = r16 ? 2u : 4u;
+    const unsigned cstride = (unsigned)p.Cout * eso, rstride = (unsigned)p.Cout * esr;
+    float* dst = split ? p.partial + ((size_t)ksplit_idx * p.N + n) * samp
+                       : reinterpret_cast<float*>(reinterpret_cast<char*>(p.out) + (size_t)n * samp * eso);
+    const __amdgpu_buffer_rsrc_t drsrc = make_rsrc(dst, (unsigned)(samp * eso));
+    const __amdgpu_buffer_rsrc_t rrsrc =
+        resid ? make_rsrc(reinterpret_cast<const char*>(p.res) + (size_t)n * samp * esr, (unsigned)(samp * esr)) : drsrc;
+    const int li = threadIdx.x & 3;
+    const bool b0 = (li & 1) != 0, b1 = (li & 2) != 0;
+    const unsigned hx = (4 * half) & (TX - 1), hy = ((4 * half) >> TXL) & (TY - 1);
+    const unsigned lane_vox = (((unsigned)z0 * p.H + y0 + hy) * p.W + x0 + hx + li);
+    unsigned wv[NJ], wr[NJ];
+    bool cv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int cout = cout0 + 32 * j;
+        cv[j] = cout < p.Cout;
+        const unsigned cq = (unsigned)(cout & ~3);
+        wv[j] = cv[j] ? lane_vox * cstride + cq * eso : DDPM3D_OOB_OFFSET;
+        wr[j] = cv[j] ? lane_vox * rstride + cq * esr : DDPM3D_OOB_OFFSET;
+    }
+    // wave-uniform voxel offset of (row tile t, register quad g), in voxels
+    unsigned so[MT][4];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int m0 = (wm * MT + t) * 32 + 8 * g;
+            const int ty = (m0 >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m0), tx = m0 & (TX - 1);
+            so[t][g] = (unsigned)((tz * p.H + ty) * p.W + tx);
+        }
+    f32x4 rq[NJ][MT][4];
+    if (resid) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (r16) rq[j][t][g] = half4_expand(__builtin_amdgcn_raw_buffer_load_b64(rrsrc, wr[j], so[t][g] * rstride, 0), f16);
+                    else rq[j][t][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, wr[j], so[t][g] * rstride, 0));
+                }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float oscale = (PREC != 0 && cv[j]) ? ws[j] * inv_act : 1.0f;
+        const float bias_w = (!split && cv[j]) ? bs[j] : 0.0f;
+        GnAcc ga[4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = PREC != 0 ? acc[j * MT + t][4 * g + i] * oscale : acc[j * MT + t][4 * g + i];
+                    a[i] = split ? v : v + bias_w;
+                }
+                quad_transpose(a, b0, b1);
+                if (!split) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (resid) a[i] += rq[j][t][g][i];
+                        if (p.stats != nullptr) {
+                            if (t == 0 && g == 0) ga[i].init(a[i]);
+                            ga[i].add(a[i]);
+                        }
+                    }
+                }
+                const unsigned sb = so[t][g] * cstride;
+                if (!split && o16)
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{half_pack(a[0], a[1], f16), half_pack(a[2], a[3], f16)}, drsrc, wv[j], sb, 0);
+                else   // (a split launch's slab: plain stores -- sc1 stores with an SGPR soffset lose a wait state, r04_sc1_store_hazard.txt)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]),
+                                                                 __builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])},
+                                                           drsrc, wv[j], sb, 0);
+            }
+        }
+        if (!split && p.stats != nullptr) {
+            // fold the quad's four voxel lanes and the two halves; then lane li keeps cout cq + li = its own
+            double d1[4], d2[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d1[i] = ga[i].sum1((float)(MT * 4));
+                d2[i] = ga[i].sum2((float)(MT * 4));
+                d1[i] += __shfl_xor(d1[i], 1); d2[i] += __shfl_xor(d2[i], 1);
+                d1[i] += __shfl_xor(d1[i], 2); d2[i] += __shfl_xor(d2[i], 2);
+                d1[i] += __shfl_xor(d1[i], 32); d2[i] += __shfl_xor(d2[i], 32);
+            }
+            const double s1 = b1 ? (b0 ? d1[3] : d1[2]) : (b0 ? d1[1] : d1[0]);
+            const double s2 = b1 ? (b0 ? d2[3] : d2[2]) : (b0 ? d2[1] : d2[0]);
+            if (half == 0 && cv[j]) {
+                const size_t row = (size_t)tile_in_n * WM + wm;
+                *reinterpret_cast<double2*>(p.stats + (((size_t)n * p.Cout + cout0 + 32 * j) * p.stats_rows + row) * 2) =
+                    make_double2(s1, s2);
+            }
+        }
+    }
+    return true;
+}
+
 // KSPLIT: the caller knows this is a split launch (p.ksplit > 1): only the slab code is instantiated.
 template <int PREC, int WM, int MT, int TXL, int TYL, bool WIDE = false, bool ZPAIRS = false, bool KSPLIT = false>
 // pre_ws / pre_bias (pre = true): p.wscale[cout] and the lane's bias, loaded by the caller at kernel

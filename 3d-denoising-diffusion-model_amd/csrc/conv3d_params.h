@@ -198,18 +198,11 @@ hipError_t ddpm3d_launch_conv_skinny(const ConvK& k, int prec, hipStream_t st); 
 hipError_t ddpm3d_launch_conv_pw(const ConvK& k, const ConvCfg& c, hipStream_t st);   // conv1x1.hip
 // the 1x1x1 convs on raw inputs (ResBlock skip connections) that conv1x1.hip's register-fed GEMM takes;
 // k is the filled launch record (chunks_per_split included)
-// The split-f16 form above 1024 workgroups (the three 256 -> 128 skip convs at 64^3: 2048 tiles, 400 MB) stays
-// on conv3d.hip's kernel: two 231-register workgroups per CU, each alive for only 8 blocks, overlap their
-// fill and drain phases worse than the general kernel's three -- 0.120 against 0.110 ms there, while every
-// smaller layer and every layer of the one-MFMA modes is 10-50 % faster here
-// (profiles/r03_layer_table_conv1x1_*.txt, r03_lib_ab_conv1x1_*.txt).
-#ifndef DDPM3D_PW_X3_MAX_WGS
-#define DDPM3D_PW_X3_MAX_WGS 1024
-#endif
+// (r03 kept the split-f16 form above 1024 workgroups -- the three 256 -> 128 skip convs at 64^3 -- on conv3d.hip's
+// kernel, 0.110 against 0.120 ms; with the lean epilogue (conv3d_epilogue.h, r04) a 1x1 workgroup is 7 k cycles
+// shorter and the order is the other way round, 0.108 against 0.115: profiles/r04_lib_ab_conv1x1_cut_lean_epilogue.txt)
 static inline bool ddpm3d_pw_ok(const ConvK& k, const ConvCfg& c, int ksize) {
     const bool s0 = (k.io & DDPM3D_IO_SRC0_BF16) != 0, s1 = (k.io & DDPM3D_IO_SRC1_BF16) != 0;
-    const long long wgs = (long long)k.N * k.tilesZ * k.tilesY * k.tilesX * (k.CoutPad / 128) * k.ksplit;
-    if (c.PREC == 1 && wgs > DDPM3D_PW_X3_MAX_WGS) return false;
     return ksize == 1 && (c.PREC == 1 || c.PREC == 2 || c.PREC == 5) && c.WN == 4 && c.MT == 4 &&
            k.in_mode == DDPM3D_IN_SAME && k.affA == nullptr && k.act == 0 && k.stats == nullptr &&
            k.Cout % 128 == 0 && k.Cin % 32 == 0 && k.C0 % 32 == 0 && (k.C1 == 0 || s0 == s1) &&

@@ -267,9 +267,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     // a split launch leaves raw slabs for the reduce launch: 16-byte stores in every mode (r04; the f16x3 form keeps
     // its four-byte stores for finished outputs, whose epilogue hides behind 3x the MFMA work -- a split workgroup is
     // two to eight chunks long and nothing hides its slab stores: profiles/r04_tree_ab_wide_slabs_prologue_*.txt)
+    // conv_epilogue_lean: the same arithmetic without conv_epilogue's run-time generality (false = not its case), in
+    // the ONE-MFMA modes: bf16 forward -0.8 % on the same box, the f16x3 kernels gain nothing (their epilogue hides
+    // behind three times the MFMA work and the board's power cap: profiles/r04_lib_ab_lean_epilogue.txt) -- and the
+    // f16x3 4x4x8 form, one register short with it, spilled pre_ws to scratch and the published network stopped
+    // being repeatable run to run (every conv test still green): those kernels keep conv_epilogue, i.e. the code
+    // this round's goldens were checked on.
+#ifndef DDPM3D_WZ_LEAN
+#define DDPM3D_WZ_LEAN 1        // measurement: 0 = conv_epilogue everywhere
+#endif
+    constexpr bool LEAN = DDPM3D_WZ_LEAN && MODE != WZ_F16X3;
+    const float ws1[1] = {pre_ws}, bs1[1] = {pre_bias};
     if (p.ksplit > 1) {
+        if (LEAN && conv_epilogue_lean<1, 1, 4, 1, TXL, TYL, G::NZP != 1, true>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half,
+                                                                                         wg.split, asc.inv, ws1, bs1)) {
+        } else
         conv_epilogue<1, 1, 4, TXL, TYL, true, G::NZP != 1, true>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split,
                                                                  asc.inv, true, pre_ws, pre_bias);
+    } else if (LEAN &&
+               conv_epilogue_lean<1, 1, 4, 1, TXL, TYL, G::NZP != 1, false>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split,
+                                                                           asc.inv, ws1, bs1)) {
     } else
     conv_epilogue<1, 1, 4, TXL, TYL, MODE != WZ_F16X3 || DDPM3D_WZ_WIDE_X3, G::NZP != 1>(p, outv, n, z0, y0, x0, tile_in_n, 0, cout, half, wg.split,
                                                                  asc.inv, true, pre_ws, pre_bias);

@@ -228,8 +228,8 @@ def test_full_size_winograd_kernel_vs_cpu_conv(ci, upsampled):
 def test_full_size_skip_connection_conv_vs_cpu(precision, dims):
     """The decoder's 1x1 skip conv at its published shapes -- virtual concat 128 + 128 -> 128 -- against
     F.conv3d on the CPU: the register-fed kernel (conv1x1.hip) at 64x32x32 in the default arithmetic and at
-    64^3 in the bf16 mode (2048 workgroups, bf16 tensors), and the 64^3 layer in the default arithmetic, which
-    the library routes to the general kernel (> 1024 workgroups).  Residual accumulated in place, as the
+    64^3 in the bf16 mode (2048 workgroups, bf16 tensors), and the 64^3 layer in the default arithmetic (402 MB of
+    fp32 tensors; on the general kernel until r04's lean epilogue).  Residual accumulated in place, as the
     engine does (the conv2 of the block adds onto the skip result)."""
     import hipcall as hc
     import guided_diffusion._hip as H
