@@ -67,6 +67,24 @@ __device__ __forceinline__ constexpr int epi_tz(int m) {
     return ZPAIRS ? 2 * ((((u & 1) << 5) + r) >> (TXL + TYL)) + (u >> 1) : m >> (TXL + TYL);
 }
 
+// The 8- and 16-byte buffer stores of the epilogues.  gfx950 reads the FIRST data register of such a store late for the
+// last four lanes of a 16-lane row: a VALU write to it shortly behind the store can overtake the read, and the lane
+// stores the NEXT group's value (one element per 16-cout run, different ones from run to run, only under load).  The
+// compiler places no wait state here -- for 16 bytes because the store's soffset is an SGPR (the documented gfx9
+// exemption), for 8 bytes never -- so how close the overwrite comes is the scheduler's choice: r03's 16-byte epilogue
+// never showed it, its write-through (sc1) form did (profiles/r04_sc1_store_hazard.txt), and the lean epilogue below
+// showed it with plain stores in three layers of the bf16 network (profiles/r04_store_data_hazard_plain.txt).
+// The asm pins the data registers for eight wait states behind the store ("+v": no value can be allocated to them
+// before it; "memory": it stays behind the store).
+__device__ __forceinline__ void epi_store_b128(u32x4 d, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, voff, soff, 0);
+    asm volatile("s_nop 7" : "+v"(d) : : "memory");
+}
+__device__ __forceinline__ void epi_store_b64(u32x2 d, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, voff, soff, 0);
+    asm volatile("s_nop 7" : "+v"(d) : : "memory");
+}
+
 // ---- The lean 16-byte epilogue (r04).  conv_epilogue below decides everything at run time and computes, before its
 // first branch, what every one of its paths needs (sample sizes and residual bases of the up / down forms, both store
 // forms' lane offsets, 64-bit products): ~500 scalar instructions that a wave issues one by one, with half of its
@@ -163,11 +181,10 @@ __device__ __forceinline__ bool conv_epilogue_lean(const ConvK& p, const f32x16 
                 }
                 const unsigned sb = so[t][g] * cstride;
                 if (!split && o16)
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{half_pack(a[0], a[1], f16), half_pack(a[2], a[3], f16)}, drsrc, wv[j], sb, 0);
-                else   // (a split launch's slab: plain stores -- sc1 stores with an SGPR soffset lose a wait state, r04_sc1_store_hazard.txt)
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]),
-                                                                 __builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])},
-                                                           drsrc, wv[j], sb, 0);
+                    epi_store_b64(u32x2{half_pack(a[0], a[1], f16), half_pack(a[2], a[3], f16)}, drsrc, wv[j], sb);
+                else
+                    epi_store_b128(u32x4{__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]),
+                                         __builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])}, drsrc, wv[j], sb);
             }
         }
         if (!split && p.stats != nullptr) {
@@ -317,19 +334,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& p, const f32x16 (&acc
                         const int m0 = (wm * MT + t) * 32 + 8 * g;
                         const int ty = (m0 >> TXL) & (TY - 1), tz = epi_tz<TXL, TYL, ZPAIRS>(m0), tx = m0 & (TX - 1);
                         const unsigned so = (unsigned)((tz * p.H + ty) * p.W + tx) * cstride;
-                        // raw slab of a split launch (the reduce launch reads it): plain 16-byte stores.  (Write-through
-                        // sc1 stores with an SGPR soffset lose a store-data wait state: profiles/r04_sc1_store_hazard.txt.)
+                        // raw slab of a split launch (the reduce launch reads it): plain 16-byte stores (epi_store_b128)
                         if (split)
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]),
-                                                                         __builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])},
-                                                                   drsrc, wv, so, 0);
+                            epi_store_b128(u32x4{__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]),
+                                                 __builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])}, drsrc, wv, so);
                         else if (KSPLIT) { }
                         else if (o16)
-                            __builtin_amdgcn_raw_buffer_store_b64(u32x2{half_pack(a[0], a[1], f16), half_pack(a[2], a[3], f16)}, drsrc, wv, so, 0);
+                            epi_store_b64(u32x2{half_pack(a[0], a[1], f16), half_pack(a[2], a[3], f16)}, drsrc, wv, so);
                         else
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]),
-                                                                         __builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])},
-                                                                   drsrc, wv, so, 0);
+                            epi_store_b128(u32x4{__builtin_bit_cast(unsigned, a[0]), __builtin_bit_cast(unsigned, a[1]),
+                                                 __builtin_bit_cast(unsigned, a[2]), __builtin_bit_cast(unsigned, a[3])}, drsrc, wv, so);
                     }
                 }
                 if (!split && p.stats != nullptr) {

@@ -268,11 +268,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_wz_kernel(const ConvK p) {
     // its four-byte stores for finished outputs, whose epilogue hides behind 3x the MFMA work -- a split workgroup is
     // two to eight chunks long and nothing hides its slab stores: profiles/r04_tree_ab_wide_slabs_prologue_*.txt)
     // conv_epilogue_lean: the same arithmetic without conv_epilogue's run-time generality (false = not its case), in
-    // the ONE-MFMA modes: bf16 forward -0.8 % on the same box, the f16x3 kernels gain nothing (their epilogue hides
-    // behind three times the MFMA work and the board's power cap: profiles/r04_lib_ab_lean_epilogue.txt) -- and the
-    // f16x3 4x4x8 form, one register short with it, spilled pre_ws to scratch and the published network stopped
-    // being repeatable run to run (every conv test still green): those kernels keep conv_epilogue, i.e. the code
-    // this round's goldens were checked on.
+    // the ONE-MFMA modes: bf16 forward -0.8 % on the same box.  The f16x3 kernels gain nothing from it (their epilogue
+    // hides behind three times the MFMA work and the board's power cap: profiles/r04_lib_ab_lean_epilogue.txt) and keep
+    // conv_epilogue.  (Both forms store through epi_store_b64 / _b128: see the store-data hazard note there.)
 #ifndef DDPM3D_WZ_LEAN
 #define DDPM3D_WZ_LEAN 1        // measurement: 0 = conv_epilogue everywhere
 #endif

@@ -126,6 +126,9 @@ def test_c4_ddim50_published_fp16_mode_psnr():
     assert model.dtype == torch.float16
     out = diff.ddim_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
     assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6   # last step is clipped x0
+    # the 50-step chain is repeatable bit for bit in this mode too (its kernels are not the default mode's)
+    again = diff.ddim_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
+    assert torch.equal(out, again)
     mse = float(((out - ref) ** 2).mean())
     psnr = 10 * np.log10(4.0 / max(mse, 1e-30))
     print("config 4 (ddim50, f16 operands) PSNR vs f16x3: %.1f dB" % psnr)
@@ -145,6 +148,8 @@ def test_c4_ddim50_published_bf16_mode_psnr():
     model.convert_to_bf16()
     out = diff.ddim_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
     assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6
+    again = diff.ddim_sample_loop(model, shape, draws[0], model_kwargs={"low_res": lr}, step_noise=draws[1:])
+    assert torch.equal(out, again)                     # bitwise repeatable over the 50-step chain
     mse = float(((out - ref) ** 2).mean())
     psnr = 10 * np.log10(4.0 / max(mse, 1e-30))
     print("config 4 (ddim50, bf16 operands + bf16 residual stream) PSNR vs f16x3: %.1f dB" % psnr)

@@ -470,6 +470,9 @@ def test_step_graph_replay_equals_eager_launches():
     ("tiny bf16", {}, (1, 1, 8, 16, 16), [500], "bf16"),
     ("tiny f16", {}, (1, 1, 8, 16, 16), [500], "f16"),
     ("published", None, (1, 1, 8, 32, 32), [251], "f16x3"),
+    # (the one-MFMA modes run the lean epilogue in their Winograd kernels, split levels and 4x4x8 tiles included)
+    ("published bf16", None, (1, 1, 8, 32, 32), [251], "bf16"),
+    ("published f16", None, (1, 1, 8, 32, 32), [251], "f16"),
 ])
 def test_native_plan_equals_python_plan(tag, over, shape, t, precision):
     """The whole-network level of the C ABI (ddpm3d_unet_plan_create / ddpm3d_unet_forward: libddpm3d compiles the
