@@ -408,8 +408,10 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_v4_kernel(const ConvK 
                     }
                     if (p.io & DDPM3D_IO_OUT_BF16) {
                         const bool f16 = (p.io & DDPM3D_IO_HALF_IS_F16) != 0;
-                        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + e) =
-                            u32x2{half_pack(val[0], val[1], f16), half_pack(val[2], val[3], f16)};
+                        u32x2 pk = u32x2{half_pack(val[0], val[1], f16), half_pack(val[2], val[3], f16)};
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(p.out) + e) = pk;
+                        // (8-byte store in a loop: data registers pinned behind it, conv3d_epilogue.h epi_store_b64)
+                        asm volatile("s_nop 7" : "+v"(pk) : : "memory");
                     }
                     else
                         *reinterpret_cast<f32x4*>(p.out + e) = val;
