@@ -1030,3 +1030,44 @@ def test_absmax_is_exact_and_order_free(hc):
         H.check(lib.ddpm3d_absmax(H.ptr(u), 0, N, per, H.ptr(b1), H.stream()))
         torch.cuda.synchronize()
         assert torch.equal(b1, u.reshape(N, per).abs().amax(dim=1))
+
+
+@pytest.mark.parametrize("case", ["bf16 concat 8-byte stores", "f16x3 split slabs", "bf16 1x1 concat", "f16 residual in place"])
+def test_conv3d_wide_epilogue_stores_are_repeatable(hc, case):
+    """r04: gfx950 reads the first data register of an 8- / 16-byte buffer store late for the last lanes of a row; a
+    VALU write scheduled shortly behind the store can overtake it (profiles/r04_store_data_hazard_plain.txt: the lean
+    epilogue made three launches of the bf16 network differ from run to run in 25-1850 bytes, 1-2 launches of 13, with
+    every accuracy test green).  Every epilogue store now pins its data registers (conv3d_epilogue.h epi_store_*);
+    this holds the affected launch shapes to bitwise repeatability over 40 launches each, output and statistics."""
+    import guided_diffusion._hip as H
+    if case == "bf16 concat 8-byte stores":         # the decoder's 256 -> 128 conv at the top level of the 8x32x32 network
+        srcs = [hc.to_ndhwc(rnd(1, 128, 8, 32, 32, seed=71)).bfloat16().cuda(), hc.to_ndhwc(rnd(1, 128, 8, 32, 32, seed=72)).bfloat16().cuda()]
+        w, kw, dhw = rnd(128, 256, 3, 3, 3, seed=73, scale=0.03), dict(precision=6, out_bf16=True), (8, 32, 32)
+    elif case == "f16x3 split slabs":               # 4x4x8 tiles, 16-way split: 16-byte slab stores + reduce
+        srcs = [hc.to_ndhwc(rnd(1, 512, 16, 4, 4, seed=74)).cuda()]
+        w, kw, dhw = rnd(512, 512, 3, 3, 3, seed=75, scale=0.02), dict(precision=3), (16, 4, 4)
+    elif case == "bf16 1x1 concat":                 # conv1x1.hip, lean epilogue over four cout blocks
+        srcs = [hc.to_ndhwc(rnd(1, 128, 8, 32, 32, seed=76)).bfloat16().cuda(), hc.to_ndhwc(rnd(1, 128, 8, 32, 32, seed=77)).bfloat16().cuda()]
+        w, kw, dhw = rnd(128, 256, 1, 1, 1, seed=78, scale=0.05), dict(precision=5, out_bf16=True, want_stats=False), (8, 32, 32)
+    else:                                           # f16 tensors, same-shape residual read behind the same kind of loads
+        srcs = [hc.to_ndhwc(rnd(1, 128, 8, 32, 32, seed=79)).half().cuda()]
+        res = hc.to_ndhwc(rnd(1, 128, 8, 32, 32, seed=80)).half().cuda()
+        w = rnd(128, 128, 3, 3, 3, seed=81, scale=0.03)
+        kw, dhw = dict(precision=4, out_f16=True, res=res, res_mode=H.RES_SAME), (8, 32, 32)
+    b = rnd(w.shape[0], seed=82).cuda()
+    A = (1.0 + 0.1 * rnd(1, w.shape[1], seed=83)).cuda()
+    B = (0.1 * rnd(1, w.shape[1], seed=84)).cuda()
+    if w.shape[2] == 3:
+        kw.update(aff=(A, B), act=H.ACT_SILU)
+    first = None
+    for it in range(40):
+        out, stats, _ = hc.conv3d(srcs, w.cuda(), b, dhw, **kw)
+        assert torch.isfinite(out.float()).all()
+        got = (out.clone(), None if stats is None else stats.clone())
+        if first is None:
+            first = got
+            if case == "f16x3 split slabs":
+                assert hc.LAST_PLAN["split"] >= 8
+        else:
+            assert torch.equal(got[0], first[0]), (case, it)
+            assert first[1] is None or torch.equal(got[1], first[1]), (case, it)
