@@ -76,13 +76,16 @@ __device__ __forceinline__ constexpr int epi_tz(int m) {
 // showed it with plain stores in three layers of the bf16 network (profiles/r04_store_data_hazard_plain.txt).
 // The asm pins the data registers for eight wait states behind the store ("+v": no value can be allocated to them
 // before it; "memory": it stays behind the store).
+#ifndef DDPM3D_EPI_PIN
+#define DDPM3D_EPI_PIN "s_nop 7"     // measurement builds: "s_nop 0", "" (pin without wait states), ...
+#endif
 __device__ __forceinline__ void epi_store_b128(u32x4 d, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, voff, soff, 0);
-    asm volatile("s_nop 7" : "+v"(d) : : "memory");
+    asm volatile(DDPM3D_EPI_PIN : "+v"(d) : : "memory");
 }
 __device__ __forceinline__ void epi_store_b64(u32x2 d, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, voff, soff, 0);
-    asm volatile("s_nop 7" : "+v"(d) : : "memory");
+    asm volatile(DDPM3D_EPI_PIN : "+v"(d) : : "memory");
 }
 
 // ---- The lean 16-byte epilogue (r04).  conv_epilogue below decides everything at run time and computes, before its
