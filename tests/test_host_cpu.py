@@ -315,3 +315,20 @@ int main(void) {
     assert [int(v) for v in out[2].split()] == [ctypes.sizeof(U), U.layers.offset, U.input_block_layers.offset,
                                                 U.output_block_layers.offset, U.first.offset, U.out.offset,
                                                 U.arithmetic.offset]
+
+
+def test_no_wide_store_is_followed_by_a_write_of_its_data_registers():
+    """gfx950 reads the first data register of an 8- / 16-byte VMEM store late, and hipcc leaves the classic
+    store-data hazard unprotected when the store's soffset is an SGPR: a VALU write placed right behind such a store
+    overtook it in r04's lean epilogue (profiles/r04_store_data_hazard_plain.txt; the GPU-side regression test is
+    test_gpu_ops.py::test_conv3d_wide_epilogue_stores_are_repeatable).  Host-side guard: no kernel of the built library
+    may contain a wide buffer / global / flat store whose data registers a VALU instruction rewrites within the next
+    two instructions (tools/check_store_hazard.py disassembles every code object of libddpm3d.so)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_store_hazard.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " 0 wide stores" in r.stdout
