@@ -229,14 +229,26 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(
     float m2 = 0.0f;                                  // largest sum of squares of any row of the group
     const size_t items = (size_t)rows * cg;          // double2 count
     const double2* run = reinterpret_cast<const double2*>(st + ((size_t)n * Cs + cs) * rows * 2);
-    // unrolled: eight independent 16-byte loads in flight per thread instead of a load -> add chain
-    // (a 64^3-level group is 128 KB: 32 loads per thread)
-#pragma unroll 8
-    for (size_t i = threadIdx.x; i < items; i += blockDim.x) {
-        const double2 v = run[i];
-        s1 += v.x;
-        s2 += v.y;
-        m2 = fmaxf(m2, (float)v.y);
+    // Eight 16-byte loads in flight per thread, UNCONDITIONALLY: buffer loads past the run return zeros, which change
+    // neither sum nor maximum.  (r01-r04 had `#pragma unroll 8` on a loop with a run-time trip count: what came out
+    // was eight guarded loads, each behind an s_waitcnt vmcnt(0) -- eight dependent round trips for the 64^3 level's
+    // eight items per thread, 12-15 us of the kernel's 5 us floor.  Same additions in the same order.)
+    {
+        const unsigned bytes = items * 16 < 0xFFFFFFF0ull ? (unsigned)(items * 16) : 0xFFFFFFF0u;
+        const __amdgpu_buffer_rsrc_t rr = make_rsrc(run, bytes);
+        const unsigned step = blockDim.x * 16u;
+        for (size_t i0 = 0; i0 < items; i0 += (size_t)blockDim.x * 8) {
+            u32x4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = buffer_load16(rr, (unsigned)(i0 + threadIdx.x) * 16u + k * step, 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const double2 v = __builtin_bit_cast(double2, t[k]);
+                s1 += v.x;
+                s2 += v.y;
+                m2 = fmaxf(m2, (float)v.y);
+            }
+        }
     }
     __shared__ double red[2][16];
     __shared__ float redm[16], redab[2][16];
